@@ -1,0 +1,79 @@
+"""Global settings of the GA3C engine, read as class attributes exactly like the reference's
+Config (/root/reference/ga3c/Config.py:27-202) and overridable from argv as KEY=VALUE
+(GA3C.py:39-43).  Names and meanings are the reference's; defaults are the ones SURVEY.md §8-d
+fixes for the 84x84x4 Atari path (the fork's own defaults target Pendulum), and the block at the
+end adds the knobs this engine needs (devices, transport, return mode).
+"""
+
+
+class Config:
+    # ---- what to run -------------------------------------------------------------------------
+    GAME = 'PongDeterministic-v4'       # gym id when gym/ALE is importable; else the synthetic source
+    PLAY_MODE = False                   # greedy actions, no training, one agent (GA3C.py:46-54)
+    TRAIN_MODELS = True
+    LOAD_CHECKPOINT = False
+    LOAD_EPISODE = 0                    # 0 = latest checkpoint
+
+    # ---- workers (initial values when DYNAMIC_SETTINGS is on) ---------------------------------
+    AGENTS = 32
+    HUMAN_REF_AGENTS = 0                # pyperrace-only in the reference; kept for argv compatibility
+    PREDICTORS = 2
+    TRAINERS = 2
+    DEVICE = 'gpu:0'
+    DYNAMIC_SETTINGS = False            # ThreadDynamicAdjustment random walk over NT/NP/NA
+    DYNAMIC_SETTINGS_STEP_WAIT = 20
+    DYNAMIC_SETTINGS_INITIAL_WAIT = 10
+
+    # ---- algorithm ----------------------------------------------------------------------------
+    DISCOUNTING = True
+    DISCOUNT = 0.99
+    TIME_MAX = 5                        # rollout cut (upstream Atari value, Config.py:77 comment)
+    REWARD_CLIPPING = True
+    USE_INTERMEDIATE_REWARD = False
+    REWARD_MIN = -1
+    REWARD_MAX = 1
+    MAX_QUEUE_SIZE = 100
+    PREDICTION_BATCH_SIZE = 128
+    STACKED_FRAMES = 4
+    IMAGE_WIDTH = 84
+    IMAGE_HEIGHT = 84
+    EPISODES = 400000
+    ANNEALING_EPISODE_COUNT = 400000
+    BETA_START = 0.01
+    BETA_END = 0.01
+    LEARNING_RATE_START = 0.0003
+    LEARNING_RATE_END = 0.0003
+    RMSPROP_DECAY = 0.99
+    RMSPROP_MOMENTUM = 0.0
+    RMSPROP_EPSILON = 0.1
+    DUAL_RMSPROP = False                # out of scope; must stay False
+    USE_GRAD_CLIP = False
+    GRAD_CLIP_NORM = 40.0
+    LOG_EPSILON = 1e-6
+    TRAINING_MIN_BATCH_SIZE = 0
+    MIN_POLICY = 0.0
+    USE_LOG_SOFTMAX = False
+    DISCRATE_INPUT = True               # (sic) discrete action space: softmax policy head
+    CONTINUOUS_INPUT = False
+    USE_DDPG = False
+    USE_REPLAY_MEMORY = False
+    USE_NETWORK_TESTER = False
+    RANDOM_SEED = 12345
+
+    # ---- logging / checkpoints ----------------------------------------------------------------
+    TENSORBOARD = False                 # scalar log written as CSV under logs/<NETWORK_NAME>/
+    TENSORBOARD_UPDATE_FREQUENCY = 1000
+    SAVE_MODELS = True
+    SAVE_FREQUENCY = 1000
+    PRINT_STATS_FREQUENCY = 1
+    STAT_ROLLING_MEAN_WINDOW = 1000
+    RESULTS_FILENAME = 'results.txt'
+    NETWORK_NAME = 'network'
+
+    # ---- engine knobs (no counterpart in the reference) ----------------------------------------
+    NUM_ACTIONS = 6                     # synthetic source only (Pong 6, Breakout 4, Boxing 18)
+    RETURN_MODE = 'fork'                # 'fork': ProcessAgent.py:69-84 bit-exact; 'nstep': upstream n-step
+    STATE_TRANSPORT = 'u8'              # 'u8': ship uint8 frames, convert on GPU; 'f32': ship f32 states
+    SYNTHETIC_EPISODE_LENGTH = 1000
+    TRAIN_ROWS_MAX = 0                  # capacity of one train call; 0 = derive from the batch knobs
+    QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often

@@ -1,0 +1,262 @@
+"""Network -- the reference's model object, backed by libga3c_hip.so instead of a TensorFlow session.
+
+Same constructor and methods as the reference's discrete-action Network
+(/root/reference/ga3c/NetworkVP.py:36-64,230-288 and NetworkVP_discrate.py:35-130), so Server,
+ThreadPredictor and ThreadTrainer call it unchanged:
+    Network(device, model_name, num_actions, state_dim)
+    predict_p_and_v(x) -> [p, v]      train(x, y_r, a, x2, done, trainer_id)
+    log(...)  save(episode)  load() -> episode   .learning_rate  .beta
+The graph is the A3C conv->dense head (NetworkDNav.py:80-90 topology, NetworkVP.py:212-228 layers,
+NetworkVP_discrate.py:58-85 heads/loss).  Every numeric step runs in the HIP library; this file only
+marshals numpy buffers.  If the library is missing or no gfx950 device is present it raises.
+"""
+import ctypes as C
+import glob
+import os
+import re
+import threading
+
+import numpy as np
+
+from Config import Config
+import _native as nat
+
+PARAM_ORDER = ("conv11/w", "conv11/b", "conv12/w", "conv12/b", "dense1/w", "dense1/b",
+               "logits_v/w", "logits_v/b", "logits_p/w", "logits_p/b")
+
+
+def param_shapes(num_actions):
+    return {"conv11/w": (8, 8, 4, 16), "conv11/b": (16,), "conv12/w": (4, 4, 16, 32), "conv12/b": (32,),
+            "dense1/w": (3872, 256), "dense1/b": (256,), "logits_v/w": (256, 1), "logits_v/b": (1,),
+            "logits_p/w": (256, num_actions), "logits_p/b": (num_actions,)}
+
+
+def initial_arena(num_actions, seed):
+    """U(-d, d), d = 1/sqrt(fan_in) (NetworkVP.py:214, NetworkDNav.py:258), flat in TF variable order."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shapes = param_shapes(num_actions)
+    parts = []
+    for name in PARAM_ORDER:
+        base = name.split("/")[0]
+        d = 1.0 / np.sqrt(np.prod(shapes[base + "/w"][:-1]))
+        parts.append(rng.uniform(-d, d, size=shapes[name]).astype(np.float32).ravel())
+    return np.concatenate(parts)
+
+
+def _device_ordinal(device):
+    m = re.search(r"(\d+)\s*$", str(device))
+    return int(m.group(1)) if m else 0
+
+
+class Network:
+    def __init__(self, device, model_name, num_actions, state_dim, max_batch=None, predict_lanes=None):
+        self.device = device
+        self.model_name = model_name
+        self.num_actions = int(num_actions)
+        self.state_dim = state_dim
+        self.learning_rate = Config.LEARNING_RATE_START
+        self.beta = Config.BETA_START
+        self.log_epsilon = Config.LOG_EPSILON
+        if int(np.prod(state_dim)) != nat.STATE_FLOATS:
+            raise ValueError("state_dim %r is not 84x84x4" % (state_dim,))
+        if Config.DUAL_RMSPROP:
+            raise ValueError("DUAL_RMSPROP is out of scope (SURVEY.md section 9, Q7)")
+        if max_batch is None:
+            max_batch = max(Config.PREDICTION_BATCH_SIZE,
+                            Config.TRAIN_ROWS_MAX or (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1))
+        self.max_batch = int(max_batch)
+        self._lib = nat.hip_lib()
+        cfg = nat.NetConfig()
+        cfg.device = _device_ordinal(device)
+        cfg.num_actions = self.num_actions
+        cfg.max_batch = self.max_batch
+        cfg.flags = (nat.FLAG_LOG_SOFTMAX if Config.USE_LOG_SOFTMAX else 0) | \
+                    (nat.FLAG_GRAD_CLIP if Config.USE_GRAD_CLIP else 0)
+        cfg.rmsprop_decay = Config.RMSPROP_DECAY
+        cfg.rmsprop_momentum = Config.RMSPROP_MOMENTUM
+        cfg.rmsprop_epsilon = Config.RMSPROP_EPSILON
+        cfg.log_epsilon = Config.LOG_EPSILON
+        cfg.min_policy = Config.MIN_POLICY
+        cfg.grad_clip_norm = Config.GRAD_CLIP_NORM
+        cfg.predict_lanes = int(predict_lanes or max(1, Config.PREDICTORS))
+        handle = C.c_void_p()
+        nat.check(self._lib.ga3c_net_create(C.byref(cfg), C.byref(handle)), "ga3c_net_create")
+        self._h = handle
+        n = C.c_int64()
+        nat.check(self._lib.ga3c_net_param_count(self._h, C.byref(n)))
+        self.param_count = n.value
+        self._offsets = {}
+        off = 0
+        for name in PARAM_ORDER:
+            size = int(np.prod(param_shapes(self.num_actions)[name]))
+            self._offsets[name] = (off, size)
+            off += size
+        assert off == self.param_count
+        self.set_arena(0, initial_arena(self.num_actions, Config.RANDOM_SEED))
+        self._log_lock = threading.Lock()
+        self.last_losses = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ga3c_net_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- arenas -----------------------------------------------------------------------------
+    def get_arena(self, which):
+        out = np.empty(self.param_count, dtype=np.float32)
+        nat.check(self._lib.ga3c_net_get_arena(self._h, which, nat.ptr(out), out.size), "ga3c_net_get_arena")
+        return out
+
+    def set_arena(self, which, flat):
+        flat = nat.as_f32(flat).ravel()
+        nat.check(self._lib.ga3c_net_set_arena(self._h, which, nat.ptr(flat), flat.size), "ga3c_net_set_arena")
+
+    def get_global_step(self):
+        s = C.c_int64()
+        nat.check(self._lib.ga3c_net_get_step(self._h, C.byref(s)))
+        return s.value
+
+    def get_variables_names(self):
+        return [n + ":0" for n in PARAM_ORDER]
+
+    def get_variable_value(self, name):
+        key = name[:-2] if name.endswith(":0") else name
+        off, size = self._offsets[key]
+        return self.get_arena(0)[off:off + size].reshape(param_shapes(self.num_actions)[key])
+
+    def set_variable_value(self, name, value):
+        key = name[:-2] if name.endswith(":0") else name
+        off, size = self._offsets[key]
+        arena = self.get_arena(0)
+        arena[off:off + size] = nat.as_f32(value).ravel()
+        self.set_arena(0, arena)
+
+    # ---- inference ---------------------------------------------------------------------------
+    def _predict(self, x, want_z=False):
+        b = int(x.shape[0])
+        p = np.empty((b, self.num_actions), dtype=np.float32)
+        v = np.empty((b,), dtype=np.float32)
+        z = np.empty((b, self.num_actions), dtype=np.float32) if want_z else None
+        zp = nat.ptr(z) if want_z else None
+        if x.dtype == np.uint8:
+            x = np.ascontiguousarray(x)
+            nat.check(self._lib.ga3c_net_predict_u8(self._h, nat.ptr(x, nat.u8p), b, nat.ptr(p), nat.ptr(v), zp),
+                      "ga3c_net_predict_u8")
+        else:
+            x = nat.as_f32(x)
+            nat.check(self._lib.ga3c_net_predict(self._h, nat.ptr(x), b, nat.ptr(p), nat.ptr(v), zp),
+                      "ga3c_net_predict")
+        return p, v, z
+
+    def predict_p_and_v(self, x):
+        p, v, _ = self._predict(x)
+        return [p, v]
+
+    def predict_p_v_logits(self, x):
+        return self._predict(x, want_z=True)
+
+    def predict_p(self, x):
+        return self._predict(x)[0]
+
+    def predict_v(self, x):
+        return self._predict(x)[1]
+
+    def predict_single(self, x):
+        return self.predict_p(x[None, :])[0]
+
+    # ---- training ----------------------------------------------------------------------------
+    def train(self, x, y_r, a, x2=None, done=None, trainer_id=0):
+        """x2, done and trainer_id are accepted and ignored, as in NetworkVP.py:254-257."""
+        x = nat.as_f32(x)
+        y = nat.as_f32(y_r)             # arrives as float64 (ProcessAgent.py:99); cast at the boundary
+        a = nat.as_f32(a)
+        losses = np.empty(3, dtype=np.float32)
+        nat.check(self._lib.ga3c_net_train(self._h, nat.ptr(x), nat.ptr(y), nat.ptr(a), int(x.shape[0]),
+                                           float(self.learning_rate), float(self.beta), nat.ptr(losses)),
+                  "ga3c_net_train")
+        self.last_losses = losses
+
+    def compute_grads(self, x, y_r, a):
+        x, y, a = nat.as_f32(x), nat.as_f32(y_r), nat.as_f32(a)
+        losses = np.empty(3, dtype=np.float32)
+        nat.check(self._lib.ga3c_net_compute_grads(self._h, nat.ptr(x), nat.ptr(y), nat.ptr(a), int(x.shape[0]),
+                                                   float(self.beta), nat.ptr(losses)), "ga3c_net_compute_grads")
+        return losses
+
+    def apply_grads(self):
+        nat.check(self._lib.ga3c_net_apply_grads(self._h, float(self.learning_rate)), "ga3c_net_apply_grads")
+
+    def fetch(self, name, count):
+        out = np.empty(int(count), dtype=np.float32)
+        nat.check(self._lib.ga3c_net_fetch(self._h, name.encode(), nat.ptr(out), out.size), "ga3c_net_fetch")
+        return out
+
+    # ---- data-parallel ------------------------------------------------------------------------
+    @staticmethod
+    def make_comm_id():
+        buf = np.zeros(nat.COMM_ID_BYTES, dtype=np.uint8)
+        nat.check(nat.hip_lib().ga3c_comm_make_id(nat.ptr(buf, nat.u8p)), "ga3c_comm_make_id")
+        return buf
+
+    def comm_init(self, comm_id, rank, world):
+        comm_id = np.ascontiguousarray(comm_id, dtype=np.uint8)
+        nat.check(self._lib.ga3c_net_comm_init(self._h, nat.ptr(comm_id, nat.u8p), rank, world), "ga3c_net_comm_init")
+
+    # ---- logging / checkpoints -----------------------------------------------------------------
+    def log(self, x, y_r, a, training_step, feed_dict=None):
+        """Scalar summaries of NetworkVP_discrate.py:132-139 appended to logs/<model>/scalars.csv."""
+        if self.last_losses is None:
+            return
+        os.makedirs("logs/%s" % self.model_name, exist_ok=True)
+        c1, c2, cv = (float(t) for t in self.last_losses)
+        with self._log_lock, open("logs/%s/scalars.csv" % self.model_name, "a") as f:
+            f.write("%d,%.8g,%.8g,%.8g,%.8g,%.8g,%.8g\n" % (training_step, c1, c2, -(c1 + c2), cv,
+                                                            self.learning_rate, self.beta))
+
+    def _checkpoint_filename(self, episode):
+        return 'checkpoints/%s_%08d' % (self.model_name, episode)
+
+    def _get_episode_from_filename(self, filename):
+        return int(re.split(r'/|_|\.', filename)[2])
+
+    def save(self, episode):
+        """Own on-disk format (.npz keyed by the TF variable names + RMSProp slots + step):
+        a TF checkpoint cannot be written without TF."""
+        os.makedirs("checkpoints", exist_ok=True)
+        theta, ms, mom = self.get_arena(0), self.get_arena(1), self.get_arena(2)
+        out = {"step": np.int64(self.get_global_step())}
+        for name in PARAM_ORDER:
+            off, size = self._offsets[name]
+            shape = param_shapes(self.num_actions)[name]
+            out[name + ":0"] = theta[off:off + size].reshape(shape)
+            out[name + "/RMSProp:0"] = ms[off:off + size].reshape(shape)
+            out[name + "/RMSProp_1:0"] = mom[off:off + size].reshape(shape)
+        tmp = self._checkpoint_filename(episode) + ".tmp.npz"
+        np.savez(tmp, **out)
+        os.replace(tmp, self._checkpoint_filename(episode) + ".npz")
+
+    def load(self):
+        if Config.LOAD_EPISODE > 0:
+            filename = self._checkpoint_filename(Config.LOAD_EPISODE) + ".npz"
+        else:
+            found = sorted(glob.glob('checkpoints/%s_????????.npz' % self.model_name))
+            if not found:
+                raise FileNotFoundError("no checkpoint for %s" % self.model_name)
+            filename = found[-1]
+        with np.load(filename, allow_pickle=False) as z:
+            arenas = [np.empty(self.param_count, np.float32) for _ in range(3)]
+            for name in PARAM_ORDER:
+                off, size = self._offsets[name]
+                for arena, suffix in zip(arenas, (":0", "/RMSProp:0", "/RMSProp_1:0")):
+                    arena[off:off + size] = z[name + suffix].ravel()
+            step = int(z["step"])
+        for which, arena in enumerate(arenas):
+            self.set_arena(which, arena)
+        nat.check(self._lib.ga3c_net_set_step(self._h, step))
+        return self._get_episode_from_filename(filename[:-4])

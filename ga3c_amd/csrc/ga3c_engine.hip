@@ -1,0 +1,803 @@
+// ga3c_engine.hip -- C ABI (include/ga3c_abi.h) over the gfx950 kernels in ga3c_kernels.hpp.
+//
+// Replaces the TensorFlow session behind the reference's Network object
+// (/root/reference/ga3c/NetworkVP.py:48-59,248-257).  HBM layout per net:
+//   theta[2]   double-buffered flat f32 weight arena (TF variable order/layout), flipped by each
+//              optimizer step so concurrent predictions never see a half-applied update;
+//   grad, ms, mom   flat arenas in the same layout (grad is what RCCL all-reduces);
+//   per lane   x[B,84,84,4]  n1[B,21,21,16]  n2[B,11,11,32]  part[KS,B,256]  d1[B,256]  z,p[B,A]  v[B]
+//   train lane additionally  y_r, a, dz, dv, lossrow[B,3], dd1[B,256], dn2, dn1, slab2, slab1.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ga3c_abi.h"
+#include "ga3c_kernels.hpp"
+
+using namespace ga3c;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) return fail(GA3C_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                        \
+  } while (0)
+#define NCCLCHK(expr)                                                                             \
+  do {                                                                                            \
+    ncclResult_t _e = (expr);                                                                     \
+    if (_e != ncclSuccess) return fail(GA3C_ERCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_e), \
+                                       __FILE__, __LINE__);                                       \
+  } while (0)
+#define CHK(expr)              \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != GA3C_OK) return _r; \
+  } while (0)
+
+struct Fwd {   // forward workspace of one lane (device pointers)
+  float *x = nullptr, *n1 = nullptr, *n2 = nullptr, *part = nullptr, *d1 = nullptr, *z = nullptr, *p = nullptr,
+        *v = nullptr;
+  uint8_t* xu8 = nullptr;
+};
+
+struct Lane {
+  std::mutex mu;
+  hipStream_t st = nullptr;
+  Fwd f;
+  float* h_in = nullptr;    // pinned staging, max_batch states
+  float* h_out = nullptr;   // pinned staging, p|v|z
+  hipEvent_t read_done[2] = {nullptr, nullptr};
+};
+
+struct TrainLane {
+  std::mutex mu;
+  hipStream_t st = nullptr;
+  Fwd f;
+  float *yr = nullptr, *act = nullptr, *dz = nullptr, *dv = nullptr, *lossrow = nullptr, *dd1 = nullptr,
+        *dn2 = nullptr, *dn1 = nullptr, *slab2 = nullptr, *slab1 = nullptr, *losses = nullptr, *scales = nullptr;
+  float* h_in = nullptr;    // pinned: x | y_r | a
+  float* h_out = nullptr;   // pinned: p | v | z | losses
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+int dense_ks(int B) { return B <= 256 ? 22 : (B <= 1024 ? 11 : 2); }
+int chunk2(int B) {   // conv2 dW pixel chunk (multiple of 16)
+  const int P = B * P2;
+  int c = ((P + 255) / 256 + 15) / 16 * 16;
+  return c < 128 ? 128 : c;
+}
+int chunk1(int B) {   // conv1 dW pixel chunk (multiple of 16)
+  const int P = B * P1;
+  int c = ((P + 511) / 512 + 15) / 16 * 16;
+  return c < 112 ? 112 : c;
+}
+
+}  // namespace
+
+struct ga3c_net {
+  ga3c_net_config cfg;
+  int A = 0;
+  int maxB = 0;
+  int64_t n = 0;   // arena floats
+  float* theta[2] = {nullptr, nullptr};
+  int cur = 0;
+  float *grad = nullptr, *ms = nullptr, *mom = nullptr;
+  hipEvent_t theta_ready[2] = {nullptr, nullptr};
+  std::shared_mutex wmu;   // shared: a forward pass picking/reading theta[cur]; unique: the optimizer flip
+  std::vector<Lane*> lanes;
+  std::atomic<unsigned> rr{0};
+  TrainLane tr;
+  int64_t step = 0;
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+  TensorTable tt;
+};
+
+namespace {
+
+int dmalloc(float** p, size_t floats) {
+  HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
+  HIPCHK(hipMemset(*p, 0, floats * sizeof(float)));
+  return GA3C_OK;
+}
+
+int alloc_fwd(Fwd& f, int maxB, int A) {
+  size_t part = 0;
+  for (int b : {maxB < 256 ? maxB : 256, maxB < 1024 ? maxB : 1024, maxB}) {
+    const size_t need = (size_t)dense_ks(b) * b * HID;
+    if (need > part) part = need;
+  }
+  CHK(dmalloc(&f.x, (size_t)maxB * XS));
+  CHK(dmalloc(&f.n1, (size_t)maxB * N1S));
+  CHK(dmalloc(&f.n2, (size_t)maxB * FLAT));
+  CHK(dmalloc(&f.part, part));
+  CHK(dmalloc(&f.d1, (size_t)maxB * HID));
+  CHK(dmalloc(&f.z, (size_t)maxB * A));
+  CHK(dmalloc(&f.p, (size_t)maxB * A));
+  CHK(dmalloc(&f.v, (size_t)maxB));
+  HIPCHK(hipMalloc((void**)&f.xu8, (size_t)maxB * XS));
+  return GA3C_OK;
+}
+
+void free_fwd(Fwd& f) {
+  for (float* p : {f.x, f.n1, f.n2, f.part, f.d1, f.z, f.p, f.v})
+    if (p) (void)hipFree(p);
+  if (f.xu8) (void)hipFree(f.xu8);
+}
+
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
+int launch_forward(ga3c_net* net, const Fwd& f, const float* th, int B, hipStream_t st, bool train,
+                   const TrainLane* tl, float beta) {
+  if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
+  const int A = net->A;
+  {
+    const int M = B * P1, nt = (M + 15) / 16;
+    int blocks = (nt + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, M, nt);
+  }
+  {
+    const int M = B * P2, nt = (M + 15) / 16;
+    int blocks = (nt + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(blocks), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, M, nt);
+  }
+  const int ks = dense_ks(B);
+  hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 15) / 16, ks), dim3(256), 0, st, f.n2, th + OFF_WD, f.part, B,
+                     KSTEPS_DENSE / ks);
+  HeadArgs h;
+  memset(&h, 0, sizeof h);
+  h.part = f.part; h.ks = ks; h.B = B; h.A = A;
+  h.bd = th + OFF_BD; h.wv = th + OFF_WV; h.bv = th + OFF_BV; h.wp = th + OFF_WP; h.bp = th + off_bp(A);
+  h.d1 = f.d1; h.z = f.z; h.p = f.p; h.v = f.v;
+  h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
+  h.log_softmax = (net->cfg.flags & GA3C_FLAG_LOG_SOFTMAX) ? 1 : 0;
+  if (train) {
+    h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.beta = beta;
+    hipLaunchKernelGGL(heads_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, st, h);
+  } else {
+    hipLaunchKernelGGL(heads_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, st, h);
+  }
+  HIPCHK(hipGetLastError());
+  return GA3C_OK;
+}
+
+int launch_backward(ga3c_net* net, const float* th, int B) {
+  TrainLane& t = net->tr;
+  const int A = net->A;
+  hipStream_t st = t.st;
+  float* g = net->grad;
+  HeadBwdArgs hb;
+  hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.wp = th + OFF_WP; hb.wv = th + OFF_WV;
+  hb.lossrow = t.lossrow; hb.dd1 = t.dd1; hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV;
+  hb.g_bv = g + OFF_BV; hb.losses = t.losses;
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B + A + 2), dim3(256), 0, st, hb);
+  hipLaunchKernelGGL(dense1_dw_kernel, dim3(FLAT / 32, 2), dim3(256), 0, st, t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD, B);
+  hipLaunchKernelGGL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), dim3(256), 0, st, t.dd1,
+                     th + OFF_WD, t.f.n2, t.dn2, B);
+  {
+    const int P = B * P2, ch = chunk2(B), nch = (P + ch - 1) / ch;
+    hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch, 2), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, P, ch);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB2 + 255) / 256), dim3(256), 0, st, t.slab2, nch, SLAB2, 256 * 32,
+                       g + OFF_W2, g + OFF_B2);
+  }
+  {
+    const int nt = (B * P2 + 15) / 16;
+    int blocks = (nt + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(conv2_dx_kernel, dim3(blocks, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+  }
+  {
+    const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
+    hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, P, ch);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB1 + 255) / 256), dim3(256), 0, st, t.slab1, nch, SLAB1, 256 * 16,
+                       g + OFF_W1, g + OFF_B1);
+  }
+  HIPCHK(hipGetLastError());
+  return GA3C_OK;
+}
+
+int launch_rmsprop(ga3c_net* net, const float* tin, float* tout, float lr, hipStream_t st) {
+  const bool clip = net->cfg.flags & GA3C_FLAG_GRAD_CLIP;
+  const bool mom = net->cfg.rmsprop_momentum != 0.0f;
+  const float omr = 1.0f - net->cfg.rmsprop_decay;
+  int blocks = (int)((net->n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (clip)
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(10), dim3(256), 0, st, net->grad, net->tt, net->cfg.grad_clip_norm,
+                       net->tr.scales);
+#define RMS(C, M)                                                                                                \
+  hipLaunchKernelGGL((rmsprop_kernel<C, M>), dim3(blocks), dim3(256), 0, st, tin, tout, net->ms, net->mom,        \
+                     net->grad, net->n, lr, omr, net->cfg.rmsprop_momentum, net->cfg.rmsprop_epsilon, net->tt,    \
+                     net->tr.scales)
+  if (clip && mom) RMS(true, true);
+  else if (clip) RMS(true, false);
+  else if (mom) RMS(false, true);
+  else RMS(false, false);
+#undef RMS
+  HIPCHK(hipGetLastError());
+  return GA3C_OK;
+}
+
+// forward on a prediction lane: pick the current weights under the shared lock
+int lane_forward(ga3c_net* net, Lane& L, int B) {
+  std::shared_lock<std::shared_mutex> lk(net->wmu);
+  const int idx = net->cur;
+  HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
+  CHK(launch_forward(net, L.f, net->theta[idx], B, L.st, false, nullptr, 0.f));
+  HIPCHK(hipEventRecord(L.read_done[idx], L.st));
+  return GA3C_OK;
+}
+
+// gradients of the batch staged in the train lane -> net->grad (train lane mutex held by caller)
+int train_grads(ga3c_net* net, int B, float beta) {
+  const float* th;
+  {
+    std::shared_lock<std::shared_mutex> lk(net->wmu);
+    th = net->theta[net->cur];   // only this lane's stream ever flips it, and that is ordered behind us
+  }
+  CHK(launch_forward(net, net->tr.f, th, B, net->tr.st, true, &net->tr, beta));
+  CHK(launch_backward(net, th, B));
+  return GA3C_OK;
+}
+
+int train_apply(ga3c_net* net, float lr) {
+  TrainLane& t = net->tr;
+  if (net->comm && net->world > 1)
+    NCCLCHK(ncclAllReduce(net->grad, net->grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  const int idx = net->cur, other = 1 - idx;
+  for (Lane* L : net->lanes) HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
+  CHK(launch_rmsprop(net, net->theta[idx], net->theta[other], lr, t.st));
+  HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
+  net->cur = other;
+  net->step += 1;
+  return GA3C_OK;
+}
+
+int stage_train_inputs(ga3c_net* net, const float* x, const float* y_r, const float* a, int B) {
+  TrainLane& t = net->tr;
+  if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
+  const size_t xb = (size_t)B * XS * sizeof(float);
+  if (x) {
+    if (is_pinned(x)) {
+      HIPCHK(hipMemcpyAsync(t.f.x, x, xb, hipMemcpyHostToDevice, t.st));
+    } else {
+      memcpy(t.h_in, x, xb);
+      HIPCHK(hipMemcpyAsync(t.f.x, t.h_in, xb, hipMemcpyHostToDevice, t.st));
+    }
+  }
+  float* hy = t.h_in + (size_t)net->maxB * XS;
+  float* ha = hy + net->maxB;
+  if (y_r) {
+    memcpy(hy, y_r, (size_t)B * sizeof(float));
+    HIPCHK(hipMemcpyAsync(t.yr, hy, (size_t)B * sizeof(float), hipMemcpyHostToDevice, t.st));
+  }
+  if (a) {
+    memcpy(ha, a, (size_t)B * net->A * sizeof(float));
+    HIPCHK(hipMemcpyAsync(t.act, ha, (size_t)B * net->A * sizeof(float), hipMemcpyHostToDevice, t.st));
+  }
+  return GA3C_OK;
+}
+
+int read_losses(ga3c_net* net, float* losses) {
+  TrainLane& t = net->tr;
+  float* hl = t.h_out;
+  HIPCHK(hipMemcpyAsync(hl, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
+  HIPCHK(hipStreamSynchronize(t.st));
+  if (losses) memcpy(losses, hl, 3 * sizeof(float));
+  return GA3C_OK;
+}
+
+int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float* v, float* z) {
+  if (!net || !x || !p || !v) return fail(GA3C_EINVAL, "null argument");
+  if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  // take any free lane, else wait on the next one in round-robin order
+  Lane* L = nullptr;
+  const unsigned start = net->rr.fetch_add(1);
+  for (size_t k = 0; k < net->lanes.size() && !L; ++k) {
+    Lane* c = net->lanes[(start + k) % net->lanes.size()];
+    if (c->mu.try_lock()) L = c;
+  }
+  if (!L) {
+    L = net->lanes[start % net->lanes.size()];
+    L->mu.lock();
+  }
+  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  const int A = net->A;
+  if (u8) {
+    const size_t nb = (size_t)B * XS;
+    if (is_pinned(x)) {
+      HIPCHK(hipMemcpyAsync(L->f.xu8, x, nb, hipMemcpyHostToDevice, L->st));
+    } else {
+      memcpy(L->h_in, x, nb);
+      HIPCHK(hipMemcpyAsync(L->f.xu8, L->h_in, nb, hipMemcpyHostToDevice, L->st));
+    }
+    const int64_t n4 = (int64_t)nb / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(blocks), dim3(256), 0, L->st, L->f.xu8, L->f.x, n4);
+  } else {
+    const size_t nb = (size_t)B * XS * sizeof(float);
+    if (is_pinned(x)) {
+      HIPCHK(hipMemcpyAsync(L->f.x, x, nb, hipMemcpyHostToDevice, L->st));
+    } else {
+      memcpy(L->h_in, x, nb);
+      HIPCHK(hipMemcpyAsync(L->f.x, L->h_in, nb, hipMemcpyHostToDevice, L->st));
+    }
+  }
+  CHK(lane_forward(net, *L, B));
+  float* hp = L->h_out;
+  float* hv = hp + (size_t)net->maxB * A;
+  float* hz = hv + net->maxB;
+  HIPCHK(hipMemcpyAsync(hp, L->f.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  HIPCHK(hipMemcpyAsync(hv, L->f.v, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  HIPCHK(hipStreamSynchronize(L->st));
+  memcpy(p, hp, (size_t)B * A * sizeof(float));
+  memcpy(v, hv, (size_t)B * sizeof(float));
+  if (z) memcpy(z, hz, (size_t)B * A * sizeof(float));
+  return GA3C_OK;
+}
+
+int sync_all(ga3c_net* net) {
+  for (Lane* L : net->lanes) HIPCHK(hipStreamSynchronize(L->st));
+  HIPCHK(hipStreamSynchronize(net->tr.st));
+  return GA3C_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ga3c_last_error(void) { return g_err.c_str(); }
+
+int ga3c_device_count(int32_t* count) {
+  if (!count) return fail(GA3C_EINVAL, "null argument");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  *count = n;
+  return GA3C_OK;
+}
+
+int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
+  if (!cfg || !out) return fail(GA3C_EINVAL, "null argument");
+  if (cfg->num_actions < 1 || cfg->num_actions > GA3C_MAX_ACTIONS)
+    return fail(GA3C_EINVAL, "num_actions %d outside [1,%d]", cfg->num_actions, GA3C_MAX_ACTIONS);
+  if (cfg->max_batch < 1 || cfg->max_batch > 65536) return fail(GA3C_EINVAL, "max_batch %d outside [1,65536]", cfg->max_batch);
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(GA3C_EINVAL, "device %d not in [0,%d)", cfg->device, ndev);
+  HIPCHK(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(GA3C_ESTATE, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
+  ga3c_net* net = new (std::nothrow) ga3c_net();
+  if (!net) return fail(GA3C_EINVAL, "out of host memory");
+  net->cfg = *cfg;
+  net->A = cfg->num_actions;
+  net->maxB = cfg->max_batch;
+  net->n = arena_floats(net->A);
+  const int A = net->A, maxB = net->maxB;
+  const int64_t offs[11] = {OFF_W1, OFF_B1, OFF_W2, OFF_B2, OFF_WD, OFF_BD, OFF_WV, OFF_BV, OFF_WP, off_bp(A), net->n};
+  for (int i = 0; i < 11; ++i) net->tt.off[i] = offs[i];
+#define TRY(expr)                    \
+  do {                               \
+    int _r = (expr);                 \
+    if (_r != GA3C_OK) {             \
+      std::string keep = g_err;      \
+      ga3c_net_destroy(net);         \
+      g_err = keep;                  \
+      return _r;                     \
+    }                                \
+  } while (0)
+#define TRYHIP(expr)                                                           \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      std::string keep = std::string(#expr) + " failed: " + hipGetErrorString(_e); \
+      ga3c_net_destroy(net);                                                   \
+      g_err = keep;                                                            \
+      return GA3C_EHIP;                                                        \
+    }                                                                          \
+  } while (0)
+  for (int i = 0; i < 2; ++i) {
+    TRY(dmalloc(&net->theta[i], (size_t)net->n));
+    TRYHIP(hipEventCreateWithFlags(&net->theta_ready[i], hipEventDisableTiming));
+  }
+  TRY(dmalloc(&net->grad, (size_t)net->n));
+  TRY(dmalloc(&net->ms, (size_t)net->n));
+  TRY(dmalloc(&net->mom, (size_t)net->n));
+  {   // RMSProp `ms` slot starts at ones (TF RMSPropOptimizer._create_slots)
+    std::vector<float> ones((size_t)net->n, 1.0f);
+    TRYHIP(hipMemcpy(net->ms, ones.data(), (size_t)net->n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  int nl = cfg->predict_lanes > 0 ? cfg->predict_lanes : 2;
+  if (nl > 16) nl = 16;
+  for (int i = 0; i < nl; ++i) {
+    Lane* L = new (std::nothrow) Lane();
+    if (!L) { ga3c_net_destroy(net); return fail(GA3C_EINVAL, "out of host memory"); }
+    net->lanes.push_back(L);
+    TRYHIP(hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking));
+    TRY(alloc_fwd(L->f, maxB, A));
+    TRYHIP(hipHostMalloc((void**)&L->h_in, (size_t)maxB * XS * sizeof(float), hipHostMallocDefault));
+    TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) TRYHIP(hipEventCreateWithFlags(&L->read_done[k], hipEventDisableTiming));
+  }
+  TrainLane& t = net->tr;
+  TRYHIP(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
+  TRY(alloc_fwd(t.f, maxB, A));
+  TRY(dmalloc(&t.yr, maxB));
+  TRY(dmalloc(&t.act, (size_t)maxB * A));
+  TRY(dmalloc(&t.dz, (size_t)maxB * A));
+  TRY(dmalloc(&t.dv, maxB));
+  TRY(dmalloc(&t.lossrow, (size_t)maxB * 3));
+  TRY(dmalloc(&t.dd1, (size_t)maxB * HID));
+  TRY(dmalloc(&t.dn2, (size_t)maxB * FLAT));
+  TRY(dmalloc(&t.dn1, (size_t)maxB * N1S));
+  {
+    const int P = maxB * P2, ch = chunk2(maxB);
+    size_t nch = (size_t)(P + ch - 1) / ch;
+    if (nch < 256) nch = 256;   // smaller batches use smaller chunks but never more than 256 of them
+    TRY(dmalloc(&t.slab2, nch * SLAB2));
+    const int Pa = maxB * P1, cha = chunk1(maxB);
+    size_t ncha = (size_t)(Pa + cha - 1) / cha;
+    if (ncha < 512) ncha = 512;
+    TRY(dmalloc(&t.slab1, ncha * SLAB1));
+  }
+  TRY(dmalloc(&t.losses, 4));
+  TRY(dmalloc(&t.scales, 16));
+  TRYHIP(hipHostMalloc((void**)&t.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
+  TRYHIP(hipHostMalloc((void**)&t.h_out, ((size_t)maxB * (2 * A + 1) + 4) * sizeof(float), hipHostMallocDefault));
+  TRYHIP(hipEventCreate(&t.ev0));
+  TRYHIP(hipEventCreate(&t.ev1));
+  TRYHIP(hipDeviceSynchronize());
+#undef TRY
+#undef TRYHIP
+  *out = net;
+  return GA3C_OK;
+}
+
+int ga3c_net_destroy(ga3c_net* net) {
+  if (!net) return GA3C_OK;
+  (void)hipSetDevice(net->cfg.device);
+  (void)hipDeviceSynchronize();
+  if (net->comm) (void)ncclCommDestroy(net->comm);
+  for (Lane* L : net->lanes) {
+    free_fwd(L->f);
+    if (L->h_in) (void)hipHostFree(L->h_in);
+    if (L->h_out) (void)hipHostFree(L->h_out);
+    for (int k = 0; k < 2; ++k)
+      if (L->read_done[k]) (void)hipEventDestroy(L->read_done[k]);
+    if (L->st) (void)hipStreamDestroy(L->st);
+    delete L;
+  }
+  TrainLane& t = net->tr;
+  free_fwd(t.f);
+  for (float* p : {t.yr, t.act, t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.losses, t.scales})
+    if (p) (void)hipFree(p);
+  if (t.h_in) (void)hipHostFree(t.h_in);
+  if (t.h_out) (void)hipHostFree(t.h_out);
+  if (t.ev0) (void)hipEventDestroy(t.ev0);
+  if (t.ev1) (void)hipEventDestroy(t.ev1);
+  if (t.st) (void)hipStreamDestroy(t.st);
+  for (int i = 0; i < 2; ++i) {
+    if (net->theta[i]) (void)hipFree(net->theta[i]);
+    if (net->theta_ready[i]) (void)hipEventDestroy(net->theta_ready[i]);
+  }
+  for (float* p : {net->grad, net->ms, net->mom})
+    if (p) (void)hipFree(p);
+  delete net;
+  return GA3C_OK;
+}
+
+int ga3c_net_param_count(ga3c_net* net, int64_t* count) {
+  if (!net || !count) return fail(GA3C_EINVAL, "null argument");
+  *count = net->n;
+  return GA3C_OK;
+}
+
+static float* arena_ptr(ga3c_net* net, int which) {
+  switch (which) {
+    case 0: return net->theta[net->cur];
+    case 1: return net->ms;
+    case 2: return net->mom;
+    case 3: return net->grad;
+    default: return nullptr;
+  }
+}
+
+int ga3c_net_get_arena(ga3c_net* net, int32_t which, float* out, int64_t count) {
+  if (!net || !out) return fail(GA3C_EINVAL, "null argument");
+  if (count != net->n) return fail(GA3C_EINVAL, "count %lld != arena size %lld", (long long)count, (long long)net->n);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  CHK(sync_all(net));
+  float* src = arena_ptr(net, which);
+  if (!src) return fail(GA3C_EINVAL, "arena selector %d not in [0,3]", which);
+  HIPCHK(hipMemcpy(out, src, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+  return GA3C_OK;
+}
+
+int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t count) {
+  if (!net || !in) return fail(GA3C_EINVAL, "null argument");
+  if (count != net->n) return fail(GA3C_EINVAL, "count %lld != arena size %lld", (long long)count, (long long)net->n);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  CHK(sync_all(net));
+  float* dst = arena_ptr(net, which);
+  if (!dst) return fail(GA3C_EINVAL, "arena selector %d not in [0,3]", which);
+  HIPCHK(hipMemcpy(dst, in, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+  return GA3C_OK;
+}
+
+int ga3c_net_get_step(ga3c_net* net, int64_t* step) {
+  if (!net || !step) return fail(GA3C_EINVAL, "null argument");
+  std::shared_lock<std::shared_mutex> lk(net->wmu);
+  *step = net->step;
+  return GA3C_OK;
+}
+
+int ga3c_net_set_step(ga3c_net* net, int64_t step) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  net->step = step;
+  return GA3C_OK;
+}
+
+int ga3c_net_predict(ga3c_net* net, const float* x, int32_t batch, float* p, float* v, float* z) {
+  return predict_common(net, x, false, batch, p, v, z);
+}
+
+int ga3c_net_predict_u8(ga3c_net* net, const uint8_t* x, int32_t batch, float* p, float* v, float* z) {
+  return predict_common(net, x, true, batch, p, v, z);
+}
+
+int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch,
+                           float beta, float* losses) {
+  if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(stage_train_inputs(net, x, y_r, a, batch));
+  CHK(train_grads(net, batch, beta));
+  return read_losses(net, losses);
+}
+
+int ga3c_net_apply_grads(ga3c_net* net, float learning_rate) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(train_apply(net, learning_rate));
+  HIPCHK(hipStreamSynchronize(net->tr.st));
+  return GA3C_OK;
+}
+
+int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch,
+                   float learning_rate, float beta, float* losses) {
+  if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(stage_train_inputs(net, x, y_r, a, batch));
+  CHK(train_grads(net, batch, beta));
+  CHK(train_apply(net, learning_rate));
+  return read_losses(net, losses);
+}
+
+int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch) {
+  if (!net || !x) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(stage_train_inputs(net, x, y_r, a, batch));
+  HIPCHK(hipStreamSynchronize(net->tr.st));
+  return GA3C_OK;
+}
+
+static int resident_predict_locked(ga3c_net* net, int B) {
+  const float* th;
+  {
+    std::shared_lock<std::shared_mutex> lk(net->wmu);
+    th = net->theta[net->cur];
+  }
+  return launch_forward(net, net->tr.f, th, B, net->tr.st, false, nullptr, 0.f);
+}
+
+int ga3c_net_predict_resident(ga3c_net* net, int32_t batch) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  return resident_predict_locked(net, batch);
+}
+
+int ga3c_net_train_resident(ga3c_net* net, int32_t batch, float learning_rate, float beta) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(train_grads(net, batch, beta));
+  return train_apply(net, learning_rate);
+}
+
+int ga3c_net_sync(ga3c_net* net) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  return sync_all(net);
+}
+
+int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t iters, float learning_rate,
+                           float beta, float* elapsed_ms) {
+  if (!net || !elapsed_ms) return fail(GA3C_EINVAL, "null argument");
+  if (iters < 1 || (mode != 0 && mode != 1)) return fail(GA3C_EINVAL, "bad mode/iters");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  TrainLane& t = net->tr;
+  HIPCHK(hipEventRecord(t.ev0, t.st));
+  for (int i = 0; i < iters; ++i) {
+    if (mode == 0) {
+      CHK(resident_predict_locked(net, batch));
+    } else {
+      CHK(train_grads(net, batch, beta));
+      CHK(train_apply(net, learning_rate));
+    }
+  }
+  HIPCHK(hipEventRecord(t.ev1, t.st));
+  HIPCHK(hipEventSynchronize(t.ev1));
+  HIPCHK(hipEventElapsedTime(elapsed_ms, t.ev0, t.ev1));
+  return GA3C_OK;
+}
+
+int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32_t iters, float* elapsed_ms) {
+  if (!net || !kernel || !elapsed_ms) return fail(GA3C_EINVAL, "null argument");
+  if (iters < 1 || batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "bad batch/iters");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  TrainLane& t = net->tr;
+  const float* th = net->theta[net->cur];
+  const int B = batch;
+  const std::string k(kernel);
+  HIPCHK(hipEventRecord(t.ev0, t.st));
+  for (int i = 0; i < iters; ++i) {
+    if (k == "conv1_fwd") {
+      const int M = B * P1, nt = (M + 15) / 16;
+      int blocks = (nt + 3) / 4;
+      if (blocks > 512) blocks = 512;
+      hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, t.st, t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, M, nt);
+    } else if (k == "conv2_fwd") {
+      const int M = B * P2, nt = (M + 15) / 16;
+      int blocks = (nt + 3) / 4;
+      if (blocks > 512) blocks = 512;
+      hipLaunchKernelGGL(conv2_fwd_kernel, dim3(blocks), dim3(256), 0, t.st, t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, M, nt);
+    } else if (k == "dense1_fwd") {
+      const int ks = dense_ks(B);
+      hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 15) / 16, ks), dim3(256), 0, t.st, t.f.n2, th + OFF_WD, t.f.part,
+                         B, KSTEPS_DENSE / ks);
+    } else if (k == "conv1_dw") {
+      const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
+      hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch), dim3(256), 0, t.st, t.f.x, t.dn1, t.slab1, P, ch);
+    } else if (k == "conv2_dw") {
+      const int P = B * P2, ch = chunk2(B), nch = (P + ch - 1) / ch;
+      hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch, 2), dim3(256), 0, t.st, t.f.n1, t.dn2, t.slab2, P, ch);
+    } else if (k == "conv2_dx") {
+      const int nt = (B * P2 + 15) / 16;
+      int blocks = (nt + 3) / 4;
+      if (blocks > 256) blocks = 256;
+      hipLaunchKernelGGL(conv2_dx_kernel, dim3(blocks, 4), dim3(256), 0, t.st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+    } else if (k == "dense1_dw") {
+      hipLaunchKernelGGL(dense1_dw_kernel, dim3(FLAT / 32, 2), dim3(256), 0, t.st, t.f.n2, t.dd1, net->grad + OFF_WD,
+                         net->grad + OFF_BD, B);
+    } else if (k == "dense1_dx") {
+      hipLaunchKernelGGL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), dim3(256), 0, t.st, t.dd1,
+                         th + OFF_WD, t.f.n2, t.dn2, B);
+    } else if (k == "rmsprop") {
+      CHK(launch_rmsprop(net, net->theta[net->cur], net->theta[net->cur], 0.0f, t.st));
+    } else {
+      return fail(GA3C_EINVAL, "unknown kernel '%s'", kernel);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(t.ev1, t.st));
+  HIPCHK(hipEventSynchronize(t.ev1));
+  HIPCHK(hipEventElapsedTime(elapsed_ms, t.ev0, t.ev1));
+  return GA3C_OK;
+}
+
+int ga3c_net_fetch(ga3c_net* net, const char* name, float* out, int64_t count) {
+  if (!net || !name || !out) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  TrainLane& t = net->tr;
+  const int64_t B = net->maxB, A = net->A;
+  struct Ent { const char* n; const float* p; int64_t cap; };
+  const Ent ents[] = {{"n1", t.f.n1, B * N1S}, {"n2", t.f.n2, B * FLAT}, {"d1", t.f.d1, B * HID}, {"z", t.f.z, B * A},
+                      {"p", t.f.p, B * A}, {"v", t.f.v, B}, {"dz", t.dz, B * A}, {"dv", t.dv, B},
+                      {"dd1", t.dd1, B * HID}, {"dn2", t.dn2, B * FLAT}, {"dn1", t.dn1, B * N1S}, {"x", t.f.x, B * XS}};
+  for (const Ent& e : ents) {
+    if (strcmp(e.n, name) == 0) {
+      if (count < 1 || count > e.cap) return fail(GA3C_EINVAL, "count %lld outside [1,%lld] for '%s'", (long long)count, (long long)e.cap, name);
+      HIPCHK(hipStreamSynchronize(t.st));
+      HIPCHK(hipMemcpy(out, e.p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+      return GA3C_OK;
+    }
+  }
+  return fail(GA3C_EINVAL, "unknown buffer '%s'", name);
+}
+
+int ga3c_host_alloc(void** ptr, int64_t bytes) {
+  if (!ptr || bytes < 1) return fail(GA3C_EINVAL, "bad argument");
+  HIPCHK(hipHostMalloc(ptr, (size_t)bytes, hipHostMallocDefault));
+  return GA3C_OK;
+}
+
+int ga3c_host_free(void* ptr) {
+  if (ptr) HIPCHK(hipHostFree(ptr));
+  return GA3C_OK;
+}
+
+int ga3c_comm_make_id(uint8_t id[GA3C_COMM_ID_BYTES]) {
+  if (!id) return fail(GA3C_EINVAL, "null argument");
+  static_assert(sizeof(ncclUniqueId) <= GA3C_COMM_ID_BYTES, "ncclUniqueId larger than the ABI token");
+  ncclUniqueId uid;
+  NCCLCHK(ncclGetUniqueId(&uid));
+  memset(id, 0, GA3C_COMM_ID_BYTES);
+  memcpy(id, &uid, sizeof uid);
+  return GA3C_OK;
+}
+
+int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int32_t rank, int32_t world) {
+  if (!net || !id) return fail(GA3C_EINVAL, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(GA3C_EINVAL, "rank %d / world %d invalid", rank, world);
+  if (net->comm) return fail(GA3C_ESTATE, "communicator already attached");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  NCCLCHK(ncclCommInitRank(&net->comm, world, uid, rank));
+  net->world = world;
+  net->rank = rank;
+  return GA3C_OK;
+}
+
+int ga3c_net_allreduce_grads(ga3c_net* net) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  if (!net->comm) return fail(GA3C_ESTATE, "no communicator attached");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  NCCLCHK(ncclAllReduce(net->grad, net->grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, net->tr.st));
+  HIPCHK(hipStreamSynchronize(net->tr.st));
+  return GA3C_OK;
+}
+
+}  // extern "C"

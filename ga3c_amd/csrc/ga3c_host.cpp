@@ -1,0 +1,503 @@
+// ga3c_host.cpp -- host-only half of the GA3C hot path: bit-exact returns and the shared-memory
+// transport that replaces the reference's pickling multiprocessing.Queues (see include/ga3c_host.h).
+// No HIP here: agent processes load only this library.
+#include "../../include/ga3c_host.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <linux/futex.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[400];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+// ---- futex helpers (cross-process: no FUTEX_PRIVATE_FLAG)
+int futex_wait(std::atomic<uint32_t>* addr, uint32_t expect, int timeout_ms) {
+  struct timespec ts, *pts = nullptr;
+  if (timeout_ms >= 0) {
+    ts.tv_sec = timeout_ms / 1000;
+    ts.tv_nsec = (long)(timeout_ms % 1000) * 1000000L;
+    pts = &ts;
+  }
+  return (int)syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAIT, expect, pts, nullptr, 0);
+}
+void futex_wake(std::atomic<uint32_t>* addr, int n) {
+  syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAKE, n, nullptr, nullptr, 0);
+}
+int64_t now_ms() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (int64_t)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+
+// ---- bounded lock-free MPMC ring of u32 (sequence-per-cell scheme), laid out inside the segment
+struct Cell {
+  std::atomic<uint64_t> seq;
+  uint32_t data;
+  uint32_t pad;
+};
+struct Ring {
+  alignas(64) std::atomic<uint64_t> enq;
+  alignas(64) std::atomic<uint64_t> deq;
+  alignas(64) std::atomic<uint32_t> signal;   // bumped on every push; the futex word consumers sleep on
+  std::atomic<uint32_t> waiters;
+  uint32_t mask;
+  uint32_t pad;
+  int64_t cells_off;   // byte offset of the cell array from the segment base
+};
+
+Cell* cells(char* base, Ring* r) { return reinterpret_cast<Cell*>(base + r->cells_off); }
+
+void ring_init(char* base, Ring* r, uint32_t cap_pow2, int64_t cells_off) {
+  r->enq.store(0);
+  r->deq.store(0);
+  r->signal.store(0);
+  r->waiters.store(0);
+  r->mask = cap_pow2 - 1;
+  r->cells_off = cells_off;
+  Cell* c = cells(base, r);
+  for (uint32_t i = 0; i < cap_pow2; ++i) {
+    c[i].seq.store(i);
+    c[i].data = 0;
+  }
+}
+
+bool ring_push(char* base, Ring* r, uint32_t v) {
+  Cell* c = cells(base, r);
+  uint64_t pos = r->enq.load(std::memory_order_relaxed);
+  for (;;) {
+    Cell* cell = &c[pos & r->mask];
+    const uint64_t seq = cell->seq.load(std::memory_order_acquire);
+    const int64_t dif = (int64_t)seq - (int64_t)pos;
+    if (dif == 0) {
+      if (r->enq.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) {
+        cell->data = v;
+        cell->seq.store(pos + 1, std::memory_order_release);
+        r->signal.fetch_add(1, std::memory_order_seq_cst);
+        if (r->waiters.load(std::memory_order_seq_cst) != 0) futex_wake(&r->signal, 1);
+        return true;
+      }
+    } else if (dif < 0) {
+      return false;   // full
+    } else {
+      pos = r->enq.load(std::memory_order_relaxed);
+    }
+  }
+}
+
+bool ring_try_pop(char* base, Ring* r, uint32_t* v) {
+  Cell* c = cells(base, r);
+  uint64_t pos = r->deq.load(std::memory_order_relaxed);
+  for (;;) {
+    Cell* cell = &c[pos & r->mask];
+    const uint64_t seq = cell->seq.load(std::memory_order_acquire);
+    const int64_t dif = (int64_t)seq - (int64_t)(pos + 1);
+    if (dif == 0) {
+      if (r->deq.compare_exchange_weak(pos, pos + 1, std::memory_order_relaxed)) {
+        *v = cell->data;
+        cell->seq.store(pos + r->mask + 1, std::memory_order_release);
+        return true;
+      }
+    } else if (dif < 0) {
+      return false;   // empty
+    } else {
+      pos = r->deq.load(std::memory_order_relaxed);
+    }
+  }
+}
+
+uint32_t ring_size(Ring* r) {
+  const uint64_t e = r->enq.load(std::memory_order_acquire), d = r->deq.load(std::memory_order_acquire);
+  return e > d ? (uint32_t)(e - d) : 0;
+}
+
+constexpr uint64_t MAGIC = 0x4741334353484d31ull;   // "GA3CSHM1"
+constexpr int MAXA = 64;
+
+struct AgentMeta {   // lives right behind each agent's state bytes
+  float p[MAXA];
+  float v;
+  uint32_t req_seq;                  // written by the agent only
+  std::atomic<uint32_t> resp_seq;    // futex word: predictor -> agent
+  uint32_t pad[61];
+};
+static_assert(sizeof(AgentMeta) == 512, "AgentMeta must stay 512 bytes");
+
+struct Header {
+  uint64_t magic;
+  ga3c_shm_config cfg;
+  int64_t total_bytes;
+  int64_t agents_off, agent_stride, state_span;
+  int64_t rollouts_off, rollout_stride, ro_returns_off, ro_actions_off, ro_rows_off;
+  std::atomic<uint32_t> closed;
+  uint32_t pad;
+  Ring req, freeq, readyq;
+};
+
+int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+uint32_t pow2_at_least(uint32_t v) {
+  uint32_t p = 2;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+struct ga3c_shm {
+  char* base = nullptr;
+  int64_t bytes = 0;
+  std::string name;
+  bool owner = false;
+  Header* hdr() const { return reinterpret_cast<Header*>(base); }
+  AgentMeta* meta(int agent) const {
+    return reinterpret_cast<AgentMeta*>(base + hdr()->agents_off + agent * hdr()->agent_stride + hdr()->state_span);
+  }
+  char* rollout(int slot) const { return base + hdr()->rollouts_off + slot * hdr()->rollout_stride; }
+};
+
+namespace {
+
+// Block until an item can be popped from `r`, the segment is closed, or the timeout passes.
+int ring_pop_wait(ga3c_shm* s, Ring* r, uint32_t* v, int timeout_ms) {
+  Header* h = s->hdr();
+  const int64_t deadline = timeout_ms >= 0 ? now_ms() + timeout_ms : -1;
+  for (;;) {
+    if (ring_try_pop(s->base, r, v)) return GA3C_H_OK;
+    if (h->closed.load(std::memory_order_acquire)) return GA3C_H_ECLOSED;
+    const uint32_t sig = r->signal.load(std::memory_order_seq_cst);
+    r->waiters.fetch_add(1, std::memory_order_seq_cst);
+    int rc = GA3C_H_OK;
+    if (ring_try_pop(s->base, r, v)) {
+      r->waiters.fetch_sub(1, std::memory_order_seq_cst);
+      return GA3C_H_OK;
+    }
+    int wait_ms = -1;
+    if (deadline >= 0) {
+      const int64_t left = deadline - now_ms();
+      if (left <= 0) rc = GA3C_H_ETIMEOUT;
+      wait_ms = (int)left;
+    }
+    if (rc == GA3C_H_OK) futex_wait(&r->signal, sig, wait_ms);
+    r->waiters.fetch_sub(1, std::memory_order_seq_cst);
+    if (rc != GA3C_H_OK) return rc;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ga3c_host_last_error(void) { return g_err.c_str(); }
+
+int ga3c_returns_fork(const double* rewards, int32_t T, double gamma, double terminal_reward, int32_t discounting,
+                      int32_t use_intermediate_reward, double* out) {
+  if (T < 0 || (T > 0 && (!rewards || !out))) return fail(GA3C_H_EINVAL, "bad arguments");
+  for (int32_t t = 0; t < T; ++t) out[t] = rewards[t];
+  double reward_sum = terminal_reward;
+  for (int32_t t = T - 2; t >= 0; --t) {
+    if (discounting) {
+      reward_sum = gamma * reward_sum;
+      if (!use_intermediate_reward) out[t] = reward_sum;
+      // with intermediate rewards the reference folds r into reward_sum and stores nothing
+    }
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_returns_nstep(const double* rewards, int32_t T, double gamma, double bootstrap_value, double rmin,
+                       double rmax, double* out) {
+  if (T < 0 || (T > 1 && (!rewards || !out))) return fail(GA3C_H_EINVAL, "bad arguments");
+  double reward_sum = bootstrap_value;
+  for (int32_t t = T - 2; t >= 0; --t) {
+    double r = rewards[t];
+    r = r < rmin ? rmin : (r > rmax ? rmax : r);
+    reward_sum = gamma * reward_sum + r;
+    out[t] = reward_sum;
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out) {
+  if (!name || !cfg || !out) return fail(GA3C_H_EINVAL, "null argument");
+  if (cfg->max_agents < 1 || cfg->max_agents > 65536 || cfg->num_actions < 1 || cfg->num_actions > MAXA ||
+      cfg->state_bytes < 16 || cfg->state_bytes % 16 != 0 || cfg->train_slots < 1 || cfg->train_slots > 65536 ||
+      cfg->train_rows < 1)
+    return fail(GA3C_H_EINVAL, "bad shm config");
+  const uint32_t req_cap = pow2_at_least((uint32_t)cfg->max_agents), tr_cap = pow2_at_least((uint32_t)cfg->train_slots);
+  Header lay;
+  memset((void*)&lay, 0, sizeof lay);
+  int64_t off = round_up(sizeof(Header), 256);
+  const int64_t req_cells = off;   off = round_up(off + (int64_t)req_cap * sizeof(Cell), 256);
+  const int64_t free_cells = off;  off = round_up(off + (int64_t)tr_cap * sizeof(Cell), 256);
+  const int64_t ready_cells = off; off = round_up(off + (int64_t)tr_cap * sizeof(Cell), 4096);
+  lay.state_span = round_up(cfg->state_bytes, 256);
+  lay.agent_stride = lay.state_span + (int64_t)sizeof(AgentMeta);
+  lay.agents_off = off;
+  off = round_up(off + lay.agent_stride * cfg->max_agents, 4096);
+  lay.ro_returns_off = round_up((int64_t)cfg->train_rows * cfg->state_bytes, 256);
+  lay.ro_actions_off = lay.ro_returns_off + round_up((int64_t)cfg->train_rows * 4, 64);
+  lay.ro_rows_off = lay.ro_actions_off + round_up((int64_t)cfg->train_rows * 4, 64);
+  lay.rollout_stride = round_up(lay.ro_rows_off + 64, 256);
+  lay.rollouts_off = off;
+  off = round_up(off + lay.rollout_stride * cfg->train_slots, 4096);
+  lay.total_bytes = off;
+
+  shm_unlink(name);
+  const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0) return fail(GA3C_H_ESYS, "shm_open(%s): %s", name, strerror(errno));
+  if (ftruncate(fd, lay.total_bytes) != 0) {
+    const int e = errno;
+    close(fd);
+    shm_unlink(name);
+    return fail(GA3C_H_ESYS, "ftruncate(%lld): %s", (long long)lay.total_bytes, strerror(e));
+  }
+  void* p = mmap(nullptr, (size_t)lay.total_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) {
+    const int e = errno;
+    shm_unlink(name);
+    return fail(GA3C_H_ESYS, "mmap: %s", strerror(e));
+  }
+  ga3c_shm* s = new (std::nothrow) ga3c_shm();
+  if (!s) {
+    munmap(p, (size_t)lay.total_bytes);
+    shm_unlink(name);
+    return fail(GA3C_H_EINVAL, "out of memory");
+  }
+  s->base = (char*)p;
+  s->bytes = lay.total_bytes;
+  s->name = name;
+  s->owner = true;
+  Header* h = s->hdr();   // fresh shm pages are zero
+  h->cfg = *cfg;
+  h->total_bytes = lay.total_bytes;
+  h->agents_off = lay.agents_off; h->agent_stride = lay.agent_stride; h->state_span = lay.state_span;
+  h->rollouts_off = lay.rollouts_off; h->rollout_stride = lay.rollout_stride;
+  h->ro_returns_off = lay.ro_returns_off; h->ro_actions_off = lay.ro_actions_off; h->ro_rows_off = lay.ro_rows_off;
+  h->closed.store(0);
+  ring_init(s->base, &h->req, req_cap, req_cells);
+  ring_init(s->base, &h->freeq, tr_cap, free_cells);
+  ring_init(s->base, &h->readyq, tr_cap, ready_cells);
+  for (int i = 0; i < cfg->train_slots; ++i) ring_push(s->base, &h->freeq, (uint32_t)i);
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  h->magic = MAGIC;
+  *out = s;
+  return GA3C_H_OK;
+}
+
+int ga3c_shm_attach(const char* name, ga3c_shm** out) {
+  if (!name || !out) return fail(GA3C_H_EINVAL, "null argument");
+  const int fd = shm_open(name, O_RDWR, 0600);
+  if (fd < 0) return fail(GA3C_H_ESYS, "shm_open(%s): %s", name, strerror(errno));
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size < (off_t)sizeof(Header)) {
+    close(fd);
+    return fail(GA3C_H_ESYS, "segment %s too small", name);
+  }
+  void* p = mmap(nullptr, (size_t)st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return fail(GA3C_H_ESYS, "mmap: %s", strerror(errno));
+  Header* h = (Header*)p;
+  if (h->magic != MAGIC || h->total_bytes != (int64_t)st.st_size) {
+    munmap(p, (size_t)st.st_size);
+    return fail(GA3C_H_EINVAL, "segment %s is not a ga3c transport", name);
+  }
+  ga3c_shm* s = new (std::nothrow) ga3c_shm();
+  if (!s) {
+    munmap(p, (size_t)st.st_size);
+    return fail(GA3C_H_EINVAL, "out of memory");
+  }
+  s->base = (char*)p;
+  s->bytes = st.st_size;
+  s->name = name;
+  *out = s;
+  return GA3C_H_OK;
+}
+
+int ga3c_shm_close(ga3c_shm* shm, int32_t unlink_segment) {
+  if (!shm) return GA3C_H_OK;
+  munmap(shm->base, (size_t)shm->bytes);
+  if (unlink_segment) shm_unlink(shm->name.c_str());
+  delete shm;
+  return GA3C_H_OK;
+}
+
+int ga3c_shm_shutdown(ga3c_shm* shm) {
+  if (!shm) return fail(GA3C_H_EINVAL, "null argument");
+  Header* h = shm->hdr();
+  h->closed.store(1, std::memory_order_seq_cst);
+  for (Ring* r : {&h->req, &h->freeq, &h->readyq}) {
+    r->signal.fetch_add(1, std::memory_order_seq_cst);
+    futex_wake(&r->signal, INT32_MAX);
+  }
+  for (int a = 0; a < h->cfg.max_agents; ++a) futex_wake(&shm->meta(a)->resp_seq, INT32_MAX);
+  return GA3C_H_OK;
+}
+
+void* ga3c_shm_base(ga3c_shm* shm) { return shm ? shm->base : nullptr; }
+int64_t ga3c_shm_bytes(ga3c_shm* shm) { return shm ? shm->bytes : 0; }
+
+int ga3c_shm_get_config(ga3c_shm* shm, ga3c_shm_config* cfg) {
+  if (!shm || !cfg) return fail(GA3C_H_EINVAL, "null argument");
+  *cfg = shm->hdr()->cfg;
+  return GA3C_H_OK;
+}
+
+int64_t ga3c_shm_state_offset(ga3c_shm* shm, int32_t agent) {
+  if (!shm || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad agent id");
+  return shm->hdr()->agents_off + agent * shm->hdr()->agent_stride;
+}
+int64_t ga3c_shm_agent_stride(ga3c_shm* shm) { return shm ? shm->hdr()->agent_stride : 0; }
+int64_t ga3c_shm_rollout_offset(ga3c_shm* shm, int32_t slot) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return fail(GA3C_H_EINVAL, "bad slot id");
+  return shm->hdr()->rollouts_off + slot * shm->hdr()->rollout_stride;
+}
+int64_t ga3c_shm_rollout_stride(ga3c_shm* shm) { return shm ? shm->hdr()->rollout_stride : 0; }
+
+void* ga3c_pq_state_ptr(ga3c_shm* shm, int32_t agent) {
+  if (!shm || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return nullptr;
+  return shm->base + shm->hdr()->agents_off + agent * shm->hdr()->agent_stride;
+}
+
+int ga3c_pq_submit(ga3c_shm* shm, int32_t agent) {
+  if (!shm || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad agent id");
+  Header* h = shm->hdr();
+  if (h->closed.load(std::memory_order_acquire)) return GA3C_H_ECLOSED;
+  AgentMeta* m = shm->meta(agent);
+  if (m->req_seq != m->resp_seq.load(std::memory_order_acquire))
+    return fail(GA3C_H_EINVAL, "agent %d already has a request in flight", agent);
+  m->req_seq += 1;
+  std::atomic_thread_fence(std::memory_order_release);   // state bytes before the id becomes visible
+  if (!ring_push(shm->base, &h->req, (uint32_t)agent)) {
+    m->req_seq -= 1;
+    return fail(GA3C_H_EINVAL, "request ring full (more than max_agents requests in flight)");
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms) {
+  if (!shm || !p || !v || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad argument");
+  Header* h = shm->hdr();
+  AgentMeta* m = shm->meta(agent);
+  const uint32_t want = m->req_seq;
+  const int64_t deadline = timeout_ms >= 0 ? now_ms() + timeout_ms : -1;
+  for (;;) {
+    const uint32_t got = m->resp_seq.load(std::memory_order_acquire);
+    if (got == want) break;
+    if (h->closed.load(std::memory_order_acquire)) return GA3C_H_ECLOSED;
+    int wait_ms = -1;
+    if (deadline >= 0) {
+      const int64_t left = deadline - now_ms();
+      if (left <= 0) return GA3C_H_ETIMEOUT;
+      wait_ms = (int)left;
+    }
+    futex_wait(&m->resp_seq, got, wait_ms);
+  }
+  memcpy(p, m->p, (size_t)h->cfg.num_actions * sizeof(float));
+  *v = m->v;
+  return GA3C_H_OK;
+}
+
+int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t timeout_ms) {
+  if (!shm || !ids || max_ids < 1) return fail(GA3C_H_EINVAL, "bad argument");
+  Header* h = shm->hdr();
+  const int rc = ring_pop_wait(shm, &h->req, &ids[0], timeout_ms);
+  if (rc == GA3C_H_ETIMEOUT) return 0;
+  if (rc != GA3C_H_OK) return rc;
+  int n = 1;
+  while (n < max_ids && ring_try_pop(shm->base, &h->req, &ids[n])) ++n;
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return n;
+}
+
+int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* p, const float* v) {
+  if (!shm || !ids || !p || !v || n < 0) return fail(GA3C_H_EINVAL, "bad argument");
+  Header* h = shm->hdr();
+  const int A = h->cfg.num_actions;
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] >= (uint32_t)h->cfg.max_agents) return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[i]);
+    AgentMeta* m = shm->meta((int)ids[i]);
+    memcpy(m->p, p + (size_t)i * A, (size_t)A * sizeof(float));
+    m->v = v[i];
+    m->resp_seq.store(m->req_seq, std::memory_order_release);
+    futex_wake(&m->resp_seq, 1);
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms) {
+  if (!shm) return fail(GA3C_H_EINVAL, "null argument");
+  uint32_t slot = 0;
+  const int rc = ring_pop_wait(shm, &shm->hdr()->freeq, &slot, timeout_ms);
+  return rc == GA3C_H_OK ? (int)slot : rc;
+}
+
+void* ga3c_tq_states(ga3c_shm* shm, int32_t slot) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return nullptr;
+  return shm->rollout(slot);
+}
+float* ga3c_tq_returns(ga3c_shm* shm, int32_t slot) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return nullptr;
+  return reinterpret_cast<float*>(shm->rollout(slot) + shm->hdr()->ro_returns_off);
+}
+int32_t* ga3c_tq_actions(ga3c_shm* shm, int32_t slot) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return nullptr;
+  return reinterpret_cast<int32_t*>(shm->rollout(slot) + shm->hdr()->ro_actions_off);
+}
+
+int ga3c_tq_commit(ga3c_shm* shm, int32_t slot, int32_t rows) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return fail(GA3C_H_EINVAL, "bad slot id");
+  if (rows < 1 || rows > shm->hdr()->cfg.train_rows) return fail(GA3C_H_EINVAL, "rows %d outside [1,%d]", rows, shm->hdr()->cfg.train_rows);
+  *reinterpret_cast<int32_t*>(shm->rollout(slot) + shm->hdr()->ro_rows_off) = rows;
+  std::atomic_thread_fence(std::memory_order_release);
+  if (!ring_push(shm->base, &shm->hdr()->readyq, (uint32_t)slot)) return fail(GA3C_H_EINVAL, "ready ring full");
+  return GA3C_H_OK;
+}
+
+int ga3c_tq_pop(ga3c_shm* shm, int32_t timeout_ms) {
+  if (!shm) return fail(GA3C_H_EINVAL, "null argument");
+  uint32_t slot = 0;
+  const int rc = ring_pop_wait(shm, &shm->hdr()->readyq, &slot, timeout_ms);
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return rc == GA3C_H_OK ? (int)slot : rc;
+}
+
+int ga3c_tq_rows(ga3c_shm* shm, int32_t slot) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return fail(GA3C_H_EINVAL, "bad slot id");
+  return *reinterpret_cast<int32_t*>(shm->rollout(slot) + shm->hdr()->ro_rows_off);
+}
+
+int ga3c_tq_release(ga3c_shm* shm, int32_t slot) {
+  if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return fail(GA3C_H_EINVAL, "bad slot id");
+  if (!ring_push(shm->base, &shm->hdr()->freeq, (uint32_t)slot)) return fail(GA3C_H_EINVAL, "free ring full");
+  return GA3C_H_OK;
+}
+
+int ga3c_tq_ready_count(ga3c_shm* shm) {
+  if (!shm) return fail(GA3C_H_EINVAL, "null argument");
+  return (int)ring_size(&shm->hdr()->readyq);
+}
+
+}  // extern "C"

@@ -1,0 +1,655 @@
+// ga3c_kernels.hpp -- hand-written gfx950 (CDNA4) kernels of the NetworkVP hot path.
+//
+// All contractions run on v_mfma_f32_16x16x4_f32 (exact f32 FMA chains; the 1e-4 parity bar of
+// BASELINE.json rules out bf16).  One wave owns one or more 16x16 output tiles.  Operand
+// fragments follow the builtin's lane map (lane l: A[row l&15][k l>>4], B[k l>>4][col l&15],
+// D[row 4*(l>>4)+reg][col l&15]).  The contraction index is consumed in a permuted order
+// -- step s, lane group g, MFMA t  <->  k = 16 s + 4 g + t -- so that a lane's four k values
+// of one step are contiguous in memory and arrive as ONE 16-byte load wherever the operand
+// is k-contiguous.  Both operands of a product use the same permutation, so the sum is
+// unchanged up to f32 summation order.
+//
+// Math restated from the reference graph (paths under /root/reference/ga3c):
+//   conv + bias + ReLU   NetworkVP.py:212-228, wired as NetworkDNav.py:81-82 (SAME padding)
+//   flatten + dense      NetworkDNav.py:86-90, :256-269
+//   heads, softmax       NetworkVP_discrate.py:60,63,73-74
+//   loss                 NetworkVP_discrate.py:61,64-85
+//   RMSProp / clipping   NetworkVP_discrate.py:99-105,120-123,130
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ga3c {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int IMG = 84, CIN = 4, XS = IMG * IMG * CIN;   // 28224 floats per state
+constexpr int O1 = 21, C1 = 16, P1 = O1 * O1, N1S = P1 * C1;   // conv1 out: 441 px, 7056 floats
+constexpr int O2 = 11, C2 = 32, P2 = O2 * O2, FLAT = P2 * C2;  // conv2 out: 121 px, 3872 floats
+constexpr int HID = 256;
+constexpr int KSTEPS_DENSE = FLAT / 16;                  // 242 permuted k-steps
+constexpr int MAX_ACTIONS = 64;
+
+// parameter arena offsets (floats), TensorFlow variable order
+constexpr int64_t OFF_W1 = 0, OFF_B1 = OFF_W1 + 256 * 16, OFF_W2 = OFF_B1 + 16, OFF_B2 = OFF_W2 + 256 * 32,
+                  OFF_WD = OFF_B2 + 32, OFF_BD = OFF_WD + (int64_t)FLAT * HID, OFF_WV = OFF_BD + HID,
+                  OFF_BV = OFF_WV + HID, OFF_WP = OFF_BV + 1;
+__host__ __device__ inline int64_t off_bp(int A) { return OFF_WP + (int64_t)HID * A; }
+__host__ __device__ inline int64_t arena_floats(int A) { return off_bp(A) + A; }
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------ input conversion
+// uint8 frames -> f32 `k/128 - 1` (Environment.py:60).  Exact in f32: k/128 is exact and so is the subtraction.
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
+                                                        int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uchar4 k = reinterpret_cast<const uchar4*>(in)[i];
+    f32x4 o = {(float)k.x * 0.0078125f - 1.0f, (float)k.y * 0.0078125f - 1.0f, (float)k.z * 0.0078125f - 1.0f,
+               (float)k.w * 0.0078125f - 1.0f};
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ conv1 forward
+// n1[m][o] = relu(b1[o] + sum_k patch(m)[k] W1[k][o]),  m = (b*21+i)*21+j, k = (u*8+v)*4+c.
+// Implicit GEMM M = B*441, K = 256, N = 16.  W1 (16 KB) lives in 64 VGPRs per lane for the wave's
+// lifetime; the patch row (8 px * 4 ch = 32 contiguous floats) arrives as 16-byte loads.
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ n1,
+                                                        int M, int ntiles) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float wr[64];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wr[s * 4 + t] = w[(16 * s + 4 * g + t) * 16 + r];
+  const float bv = bias[r];
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int m = tile * 16 + r;
+    const bool valid = m < M;
+    const int mm = valid ? m : 0;
+    const int b = mm / P1, rem = mm - b * P1, i = rem / O1, j = rem - i * O1;
+    const int y0 = 4 * i - 2, x0 = 4 * j - 2 + g;
+    const float* xb = x + (size_t)b * XS;
+    f32x4 a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int yy = y0 + (s >> 1), xx = x0 + (s & 1) * 4;
+      const bool ok = valid && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+      a[s] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
+    }
+    f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma(a[s][t], wr[s * 4 + t], acc0);
+        acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = tile * 16 + 4 * g + q;
+      if (mr < M) n1[(size_t)mr * C1 + r] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ conv2 forward
+// n2[m][o] = relu(b2[o] + sum_k patch(m)[k] W2[k][o]), m = (b*11+i)*11+j, k = (u*4+v)*16+c.
+// M = B*121, K = 256, N = 32: both 16-column halves per wave (two independent MFMA chains).
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict__ n1, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ n2,
+                                                        int M, int ntiles) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float w0[64], w1[64];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      w0[s * 4 + t] = w[(16 * s + 4 * g + t) * C2 + r];
+      w1[s * 4 + t] = w[(16 * s + 4 * g + t) * C2 + 16 + r];
+    }
+  const float bv0 = bias[r], bv1 = bias[16 + r];
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int m = tile * 16 + r;
+    const bool valid = m < M;
+    const int mm = valid ? m : 0;
+    const int b = mm / P2, rem = mm - b * P2, i = rem / O2, j = rem - i * O2;
+    const int y0 = 2 * i - 1, x0 = 2 * j - 1;
+    const float* nb = n1 + (size_t)b * N1S + 4 * g;
+    f32x4 a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int yy = y0 + (s >> 2), xx = x0 + (s & 3);
+      const bool ok = valid && (unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1;
+      a[s] = ok ? ld4(nb + (yy * O1 + xx) * C1) : zero4();
+    }
+    f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma(a[s][t], w0[s * 4 + t], acc0);
+        acc1 = mfma(a[s][t], w1[s * 4 + t], acc1);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = tile * 16 + 4 * g + q;
+      if (mr < M) {
+        n2[(size_t)mr * C2 + r] = fmaxf(acc0[q] + bv0, 0.f);
+        n2[(size_t)mr * C2 + 16 + r] = fmaxf(acc1[q] + bv1, 0.f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dense1 forward (split-K)
+// part[ks][b][n] = sum_{k in slice ks} flat[b][k] Wd[k][n];  M = B, N = 256, K = 3872 = 242 steps of 16.
+// grid.x = m-tiles, grid.y = KS slices, block = 4 waves = four 64-column groups (NT = 4 tiles each).
+__global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict__ flat, const float* __restrict__ wd,
+                                                         float* __restrict__ part, int B, int steps_per_slice) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int ng = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 16, ks = blockIdx.y;
+  const int row = m0 + r;
+  const bool valid = row < B;
+  const float* arow = flat + (size_t)(valid ? row : 0) * FLAT + 4 * g;
+  const float* wcol = wd + ng * 64 + r;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  const int s0 = ks * steps_per_slice;
+  for (int s = s0; s < s0 + steps_per_slice; ++s) {
+    const f32x4 a = valid ? ld4(arow + 16 * s) : zero4();
+    float bw[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bw[t][nt] = wcol[(size_t)(16 * s + 4 * g + t) * HID + nt * 16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma(a[t], bw[t][nt], acc[nt]);
+  }
+  float* out = part + ((size_t)ks * B) * HID + ng * 64 + r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mr = m0 + 4 * g + q;
+    if (mr < B) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) out[(size_t)mr * HID + nt * 16] = acc[nt][q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ heads (+ loss)
+// One wave per sample: d1 = relu(sum_ks part + bd); z = d1 Wp + bp; v = d1 Wv + bv; softmax;
+// TRAIN adds the A3C loss terms and the head gradients dz, dv.
+struct HeadArgs {
+  const float* part; int ks; int B; int A;
+  const float* bd; const float* wv; const float* bv; const float* wp; const float* bp;
+  float* d1; float* z; float* p; float* v;
+  // train only
+  const float* y_r; const float* act; float* dz; float* dv; float* lossrow;
+  float beta, log_eps, min_policy; int log_softmax;
+};
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= h.B) return;   // wave-uniform
+  f32x4 d = ld4(h.bd + 4 * lane);
+  for (int ks = 0; ks < h.ks; ++ks) d += ld4(h.part + ((size_t)ks * h.B + b) * HID + 4 * lane);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) d[q] = fmaxf(d[q], 0.f);
+  *reinterpret_cast<f32x4*>(h.d1 + (size_t)b * HID + 4 * lane) = d;
+
+  const f32x4 wv4 = ld4(h.wv + 4 * lane);
+  const float v = wave_sum(d[0] * wv4[0] + d[1] * wv4[1] + d[2] * wv4[2] + d[3] * wv4[3]) + h.bv[0];
+  float zmine = -INFINITY;
+  for (int o = 0; o < h.A; ++o) {
+    const float* wp = h.wp + (size_t)(4 * lane) * h.A + o;
+    const float tot = wave_sum(d[0] * wp[0] + d[1] * wp[h.A] + d[2] * wp[2 * h.A] + d[3] * wp[3 * h.A]);
+    if (lane == o) zmine = tot + h.bp[o];
+  }
+  const bool mine = lane < h.A;
+  const float zmax = wave_max(zmine);
+  const float e = mine ? expf(zmine - zmax) : 0.f;
+  const float esum = wave_sum(e);
+  const float s = e / esum;
+  const float denom = 1.0f + h.min_policy * (float)h.A;
+  const float p = h.log_softmax ? s : (s + h.min_policy) / denom;
+  if (mine) {
+    h.z[(size_t)b * h.A + lane] = zmine;
+    h.p[(size_t)b * h.A + lane] = p;
+  }
+  if (lane == 0) h.v[b] = v;
+  if (TRAIN) {
+    const float y = h.y_r[b];
+    const float adv = y - v;
+    const float a = mine ? h.act[(size_t)b * h.A + lane] : 0.f;
+    float dz, c1, c2;
+    if (h.log_softmax) {
+      const float ls = mine ? (zmine - zmax) - logf(esum) : 0.f;
+      const float lsel = wave_sum(ls * a);
+      const float ent = wave_sum(mine ? s * ls : 0.f);
+      const float asum = wave_sum(a);
+      c1 = lsel * adv;
+      c2 = -h.beta * ent;
+      dz = -adv * (a - s * asum) + h.beta * s * (ls - ent);
+    } else {
+      const float sel = wave_sum(mine ? p * a : 0.f);
+      const float logp = logf(fmaxf(p, h.log_eps));
+      c1 = logf(fmaxf(sel, h.log_eps)) * adv;
+      c2 = -h.beta * wave_sum(mine ? logp * p : 0.f);
+      const float gsel = sel >= h.log_eps ? 1.0f / sel : 0.f;
+      const float gp = -(adv * gsel) * a + h.beta * (logp + (p >= h.log_eps ? 1.0f : 0.f));
+      const float gs = mine ? gp / denom : 0.f;
+      const float dot = wave_sum(gs * s);
+      dz = s * (gs - dot);
+    }
+    if (mine) h.dz[(size_t)b * h.A + lane] = dz;
+    if (lane == 0) {
+      h.dv[b] = v - y;
+      h.lossrow[(size_t)b * 3 + 0] = c1;
+      h.lossrow[(size_t)b * 3 + 1] = c2;
+      h.lossrow[(size_t)b * 3 + 2] = 0.5f * (y - v) * (y - v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ heads backward
+// blocks [0,B): dd1[b][k] = 1[d1>0] (sum_o dz[b][o] Wp[k][o] + dv[b] Wv[k])
+// blocks [B,B+A]: o = blk-B; dW[k] = sum_b d1[b][k] dhead[b] (o<A: dWp[:,o]; o==A: dWv), bias by LDS tree
+// block  B+A+1: losses[c] = sum_b lossrow[b][c], fixed order
+struct HeadBwdArgs {
+  int B; int A;
+  const float* d1; const float* dz; const float* dv; const float* wp; const float* wv; const float* lossrow;
+  float* dd1; float* g_wp; float* g_bp; float* g_wv; float* g_bv; float* losses;
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadBwdArgs h) {
+  __shared__ float sh[4];
+  const int k = threadIdx.x;
+  const int blk = blockIdx.x;
+  if (blk < h.B) {
+    const int b = blk;
+    float acc = h.dv[b] * h.wv[k];
+    for (int o = 0; o < h.A; ++o) acc += h.dz[(size_t)b * h.A + o] * h.wp[(size_t)k * h.A + o];
+    h.dd1[(size_t)b * HID + k] = h.d1[(size_t)b * HID + k] > 0.f ? acc : 0.f;
+  } else if (blk <= h.B + h.A) {
+    const int o = blk - h.B;
+    const bool isv = o == h.A;
+    float acc = 0.f, bsum = 0.f;
+    for (int b = 0; b < h.B; ++b) {
+      const float gh = isv ? h.dv[b] : h.dz[(size_t)b * h.A + o];
+      acc += h.d1[(size_t)b * HID + k] * gh;
+    }
+    for (int b = k; b < h.B; b += 256) bsum += isv ? h.dv[b] : h.dz[(size_t)b * h.A + o];
+    bsum = block_sum_256(bsum, sh);
+    if (isv) {
+      h.g_wv[k] = acc;
+      if (k == 0) h.g_bv[0] = bsum;
+    } else {
+      h.g_wp[(size_t)k * h.A + o] = acc;
+      if (k == 0) h.g_bp[o] = bsum;
+    }
+  } else {
+    for (int c = 0; c < 3; ++c) {
+      float part = 0.f;
+      for (int b = k; b < h.B; b += 256) part += h.lossrow[(size_t)b * 3 + c];
+      part = block_sum_256(part, sh);
+      if (k == 0) h.losses[c] = part;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dense1 backward: dWd = flat^T dd1
+// M = 3872 (kidx), N = 256, contraction over the batch.  Wave tile 32 x 32 (2 x 2 MFMA tiles).
+// grid.x = 121 row blocks, grid.y = 2, wave -> 32-column group (grid.y*4 + wave).
+// Row block 0 also produces dbd[n] = sum_b dd1[b][n].
+__global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dd1,
+                                                        float* __restrict__ g_wd, float* __restrict__ g_bd, int B) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 32;
+  const int n0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 32;
+  f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+  float bs0 = 0.f, bs1 = 0.f;
+  const int nsteps = (B + 15) >> 4;
+  for (int s = 0; s < nsteps; ++s) {
+    float a[4][2], bb[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int b = 16 * s + 4 * g + t;
+      const bool ok = b < B;
+      const float* fr = flat + (size_t)(ok ? b : 0) * FLAT + m0 + r;
+      const float* dr = dd1 + (size_t)(ok ? b : 0) * HID + n0 + r;
+      a[t][0] = ok ? fr[0] : 0.f;
+      a[t][1] = ok ? fr[16] : 0.f;
+      bb[t][0] = ok ? dr[0] : 0.f;
+      bb[t][1] = ok ? dr[16] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bs0 += bb[t][0];
+      bs1 += bb[t][1];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma(a[t][mi], bb[t][ni], acc[mi][ni]);
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        g_wd[(size_t)(m0 + mi * 16 + 4 * g + q) * HID + n0 + ni * 16 + r] = acc[mi][ni][q];
+  if (blockIdx.x == 0) {
+    bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
+    if (g == 0) {
+      g_bd[n0 + r] = bs0;
+      g_bd[n0 + 16 + r] = bs1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dense1 backward: dn2 = (dd1 Wd^T) * 1[n2>0]
+// M = B, N = 3872, K = 256.  Both operands are k-contiguous (16-byte loads).  Wave tile 16 x 32.
+// grid.x = 121 column blocks of 32... each block's 4 waves take 4 consecutive m-tiles; grid.y covers the rest.
+__global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict__ dd1, const float* __restrict__ wd,
+                                                        const float* __restrict__ n2, float* __restrict__ dn2, int B) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 32;
+  const int m0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+  if (m0 >= B) return;   // wave-uniform
+  const int row = m0 + r;
+  const bool valid = row < B;
+  const float* arow = dd1 + (size_t)(valid ? row : 0) * HID + 4 * g;
+  const float* b0 = wd + (size_t)(n0 + r) * HID + 4 * g;
+  const float* b1 = wd + (size_t)(n0 + 16 + r) * HID + 4 * g;
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const f32x4 a = valid ? ld4(arow + 16 * s) : zero4();
+    const f32x4 w0 = ld4(b0 + 16 * s), w1 = ld4(b1 + 16 * s);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc0 = mfma(a[t], w0[t], acc0);
+      acc1 = mfma(a[t], w1[t], acc1);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mr = m0 + 4 * g + q;
+    if (mr < B) {
+      const size_t o = (size_t)mr * FLAT + n0 + r;
+      dn2[o] = n2[o] > 0.f ? acc0[q] : 0.f;
+      dn2[o + 16] = n2[o + 16] > 0.f ? acc1[q] : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ conv2 backward: dW2 partials
+// dW2[kidx][o] = sum_q patch(q)[kidx] dn2[q][o]; kidx = (u*4+v)*16 + c, q over B*121 pixels.
+// m-tile mt = patch position (u,v), lane row = channel c.  Wave = 2 m-tiles x 32 columns.
+// grid.x = pixel chunk, grid.y = 2; wave -> m-group (grid.y*4 + wave), 8 groups of 2 positions.
+// part[chunk][8192 + 32]: the +32 tail is the chunk's db2 (written by m-group 0).
+constexpr int SLAB2 = 256 * 32 + 32;
+__global__ __launch_bounds__(256) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
+                                                       float* __restrict__ part, int P, int chunk) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int mg = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int q0 = blockIdx.x * chunk;
+  f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+  float bs0 = 0.f, bs1 = 0.f;
+  for (int s = 0; s < chunk / 16; ++s) {
+    float a[4][2], bb[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int q = q0 + 16 * s + 4 * g + t;
+      const bool ok = q < P;
+      const int qq = ok ? q : 0;
+      const int b = qq / P2, rem = qq - b * P2, i = rem / O2, j = rem - i * O2;
+      const float* dr = dn2 + (size_t)qq * C2 + r;
+      bb[t][0] = ok ? dr[0] : 0.f;
+      bb[t][1] = ok ? dr[16] : 0.f;
+      const float* nb = n1 + (size_t)b * N1S + r;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mt = mg * 2 + mi;
+        const int yy = 2 * i - 1 + (mt >> 2), xx = 2 * j - 1 + (mt & 3);
+        const bool in = ok && (unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1;
+        a[t][mi] = in ? nb[(yy * O1 + xx) * C1] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bs0 += bb[t][0];
+      bs1 += bb[t][1];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma(a[t][mi], bb[t][ni], acc[mi][ni]);
+    }
+  }
+  float* out = part + (size_t)blockIdx.x * SLAB2;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        out[((mg * 2 + mi) * 16 + 4 * g + q) * C2 + ni * 16 + r] = acc[mi][ni][q];
+  if (mg == 0) {
+    bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
+    if (g == 0) {
+      out[256 * 32 + r] = bs0;
+      out[256 * 32 + 16 + r] = bs1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ conv2 backward: dn1 (transposed conv as a gather)
+// dn1[b,y,x,c] = 1[n1>0] sum_{ua,va in {0,1}} sum_o dn2[b,i,j,o] W2[u,v,c,o],
+//   i = ((y+1)>>1) - ua, u = ((y+1)&1) + 2 ua (same for x): K = 4 taps * 32 = 128, N = 16.
+// Pixels are grouped by parity class (py,px) so that a 16-pixel tile shares one weight sub-matrix.
+template <int PY, int PX>
+__device__ __forceinline__ void conv2_dx_class(const float* __restrict__ dn2, const float* __restrict__ w,
+                                               const float* __restrict__ n1, float* __restrict__ dn1, int B) {
+  constexpr int NY = PY ? 10 : 11, NX = PX ? 10 : 11, CNT = NY * NX;
+  constexpr int PU = 1 - PY, PV = 1 - PX;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int Mc = B * CNT, ntiles = (Mc + 15) >> 4;
+  float wr[32];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int ua = s >> 2, va = (s >> 1) & 1, half = s & 1;
+    const int u = PU + 2 * ua, v = PV + 2 * va;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wr[s * 4 + t] = w[((u * 4 + v) * 16 + r) * C2 + half * 16 + 4 * g + t];
+  }
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int mc = tile * 16 + r;
+    const bool valid = mc < Mc;
+    const int mm = valid ? mc : 0;
+    const int b = mm / CNT, rem = mm - b * CNT, ya = rem / NX, xa = rem - ya * NX;
+    const int ih = (2 * ya + PY + 1) >> 1, jh = (2 * xa + PX + 1) >> 1;
+    const float* db = dn2 + (size_t)b * FLAT + 4 * g;
+    f32x4 a[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int i = ih - (s >> 2), j = jh - ((s >> 1) & 1);
+      const bool ok = valid && (unsigned)i < (unsigned)O2 && (unsigned)j < (unsigned)O2;
+      a[s] = ok ? ld4(db + (i * O2 + j) * C2 + (s & 1) * 16) : zero4();
+    }
+    f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+    for (int s = 0; s < 8; s += 2)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma(a[s][t], wr[s * 4 + t], acc0);
+        acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = tile * 16 + 4 * g + q;
+      if (mr < Mc) {
+        const int b2 = mr / CNT, rem2 = mr - b2 * CNT, ya2 = rem2 / NX, xa2 = rem2 - ya2 * NX;
+        const size_t o = (size_t)b2 * N1S + ((2 * ya2 + PY) * O1 + (2 * xa2 + PX)) * C1 + r;
+        dn1[o] = n1[o] > 0.f ? acc0[q] + acc1[q] : 0.f;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv2_dx_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
+                                                       const float* __restrict__ n1, float* __restrict__ dn1, int B) {
+  switch (blockIdx.y) {   // block-uniform
+    case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, B); break;
+    case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, B); break;
+    case 2: conv2_dx_class<1, 0>(dn2, w, n1, dn1, B); break;
+    default: conv2_dx_class<1, 1>(dn2, w, n1, dn1, B); break;
+  }
+}
+
+// ------------------------------------------------------------------ conv1 backward: dW1 partials
+// dW1[kidx][o] = sum_q patch(q)[kidx] dn1[q][o]; kidx = (u*8+v)*4+c; m-tile mt = u*2 + (v>>2),
+// lane row r = (v&3)*4 + c = 16 contiguous floats of one input row.  Wave = 4 m-tiles x 16 columns.
+// grid.x = pixel chunk; wave -> m-group.  part[chunk][4096 + 16] (+16 = db1 of the chunk).
+constexpr int SLAB1 = 256 * 16 + 16;
+__global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__ x, const float* __restrict__ dn1,
+                                                       float* __restrict__ part, int P, int chunk) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int mg = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * chunk;
+  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+  float bs = 0.f;
+  for (int s = 0; s < chunk / 16; ++s) {
+    float a[4][4], bb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int q = q0 + 16 * s + 4 * g + t;
+      const bool ok = q < P;
+      const int qq = ok ? q : 0;
+      const int b = qq / P1, rem = qq - b * P1, i = rem / O1, j = rem - i * O1;
+      bb[t] = ok ? dn1[(size_t)qq * C1 + r] : 0.f;
+      const float* xb = x + (size_t)b * XS;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int mt = mg * 4 + mi;
+        const int yy = 4 * i - 2 + (mt >> 1), xx = 4 * j - 2 + (mt & 1) * 4 + (r >> 2);
+        const bool in = ok && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+        a[t][mi] = in ? xb[(yy * IMG + xx) * 4 + (r & 3)] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bs += bb[t];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma(a[t][mi], bb[t], acc[mi]);
+    }
+  }
+  float* out = part + (size_t)blockIdx.x * SLAB1;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[((mg * 4 + mi) * 16 + 4 * g + q) * C1 + r] = acc[mi][q];
+  if (mg == 0) {
+    bs += __shfl_xor(bs, 16, 64); bs += __shfl_xor(bs, 32, 64);
+    if (g == 0) out[256 * 16 + r] = bs;
+  }
+}
+
+// ------------------------------------------------------------------ slab reduce (fixed order => reproducible)
+// out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int nchunks, int stride,
+                                                          int nw, float* __restrict__ out_w, float* __restrict__ out_b) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= stride) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    s0 += part[(size_t)c * stride + e];
+    s1 += part[(size_t)(c + 1) * stride + e];
+    s2 += part[(size_t)(c + 2) * stride + e];
+    s3 += part[(size_t)(c + 3) * stride + e];
+  }
+  for (; c < nchunks; ++c) s0 += part[(size_t)c * stride + e];
+  const float tot = (s0 + s1) + (s2 + s3);
+  if (e < nw) out_w[e] = tot; else out_b[e - nw] = tot;
+}
+
+// ------------------------------------------------------------------ gradient clipping (optional)
+// tf.clip_by_average_norm per tensor: scale = clip / max(||g||_2 / n, clip).  One block per tensor.
+struct TensorTable { int64_t off[11]; };
+__global__ __launch_bounds__(256) void clip_scale_kernel(const float* __restrict__ grad, TensorTable tt, float clip,
+                                                         float* __restrict__ scales) {
+  __shared__ float sh[4];
+  const int64_t lo = tt.off[blockIdx.x], hi = tt.off[blockIdx.x + 1];
+  float s = 0.f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += grad[i] * grad[i];
+  s = block_sum_256(s, sh);
+  if (threadIdx.x == 0) scales[blockIdx.x] = clip / fmaxf(sqrtf(s) / (float)(hi - lo), clip);
+}
+
+// ------------------------------------------------------------------ RMSProp (TF-1.x ApplyRMSProp arithmetic)
+// ms += (g*g - ms)*(1-rho); mom = mom*mu + (g*lr)/sqrt(eps+ms); theta_out = theta_in - mom.
+// theta_in/theta_out are the two halves of the double-buffered weights.
+template <bool CLIP, bool MOM>
+__global__ __launch_bounds__(256) void rmsprop_kernel(const float* __restrict__ theta_in, float* __restrict__ theta_out,
+                                                      float* __restrict__ ms, float* __restrict__ mom,
+                                                      const float* __restrict__ grad, int64_t n, float lr,
+                                                      float one_minus_rho, float mu, float eps, TensorTable tt,
+                                                      const float* __restrict__ scales) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = grad[i];
+    if (CLIP) {
+      int ti = 0;
+#pragma unroll
+      for (int k = 1; k < 10; ++k) ti += (i >= tt.off[k]) ? 1 : 0;
+      g *= scales[ti];
+    }
+    float m = ms[i];
+    m += (g * g - m) * one_minus_rho;
+    ms[i] = m;
+    float step = (g * lr) / sqrtf(eps + m);
+    if (MOM) {
+      step = mom[i] * mu + step;
+      mom[i] = step;
+    }
+    theta_out[i] = theta_in[i] - step;
+  }
+}
+
+}  // namespace ga3c

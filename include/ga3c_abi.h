@@ -1,0 +1,128 @@
+/* ga3c_abi.h -- C ABI of libga3c_hip.so, the MI355X (gfx950) NetworkVP engine.
+ *
+ * This is the drop-in boundary for the reference's `Network` object
+ * (/root/reference/ga3c, TensorFlow session calls).  Every entry point names the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++ types,
+ * no exceptions cross this boundary.  All functions return 0 on success and a
+ * negative GA3C_E* code on failure; ga3c_last_error() then holds a message for
+ * the calling thread.
+ *
+ * Threading: one ga3c_net may be called concurrently from any number of host
+ * threads (the reference calls predict from NP predictor threads and train from
+ * NT trainer threads on one object without locks, Server.py:123-134,141-153).
+ * Predictions run on per-call lanes; train steps are serialised; a prediction
+ * sees either the weights before or after a train step, never a mix.
+ */
+#ifndef GA3C_ABI_H
+#define GA3C_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA3C_OK 0
+#define GA3C_EINVAL (-1)   /* bad argument / shape */
+#define GA3C_EHIP (-2)     /* HIP runtime error */
+#define GA3C_ERCCL (-3)    /* RCCL error */
+#define GA3C_ESTATE (-4)   /* call not valid in this state */
+
+#define GA3C_FLAG_LOG_SOFTMAX 1u   /* Config.USE_LOG_SOFTMAX branch, NetworkVP_discrate.py:64-71 */
+#define GA3C_FLAG_GRAD_CLIP 2u     /* Config.USE_GRAD_CLIP, tf.clip_by_average_norm, :120-123 */
+
+#define GA3C_STATE_FLOATS 28224    /* 84*84*4 (Config.py:90-92) */
+#define GA3C_MAX_ACTIONS 64
+
+typedef struct ga3c_net ga3c_net;
+
+/* Replaces the constructor arguments + Config reads of Network.__init__
+ * (NetworkVP.py:37-46) and of the optimizer block (NetworkVP_discrate.py:99-105). */
+typedef struct ga3c_net_config {
+  int32_t device;          /* HIP device ordinal (Config.DEVICE 'gpu:N') */
+  int32_t num_actions;     /* A */
+  int32_t max_batch;       /* capacity in rows of one predict / train call */
+  uint32_t flags;          /* GA3C_FLAG_* */
+  float rmsprop_decay;     /* Config.RMSPROP_DECAY   (0.99) */
+  float rmsprop_momentum;  /* Config.RMSPROP_MOMENTUM (0.0) */
+  float rmsprop_epsilon;   /* Config.RMSPROP_EPSILON (0.1) */
+  float log_epsilon;       /* Config.LOG_EPSILON     (1e-6) */
+  float min_policy;        /* Config.MIN_POLICY      (0.0) */
+  float grad_clip_norm;    /* Config.GRAD_CLIP_NORM  (40.0), used with GA3C_FLAG_GRAD_CLIP */
+  int32_t predict_lanes;   /* concurrent prediction lanes (>=1; 0 -> 2) */
+  int32_t reserved;
+} ga3c_net_config;
+
+const char* ga3c_last_error(void);
+int ga3c_device_count(int32_t* count);
+
+/* Network.__init__ / session teardown.  Weights are zero until ga3c_net_set_params. */
+int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out);
+int ga3c_net_destroy(ga3c_net* net);
+
+/* Parameter arena.  Flat f32 in TensorFlow variable order and layout:
+ * conv11/w[8,8,4,16] conv11/b[16] conv12/w[4,4,16,32] conv12/b[32] dense1/w[3872,256]
+ * dense1/b[256] logits_v/w[256,1] logits_v/b[1] logits_p/w[256,A] logits_p/b[A].
+ * Replaces get_variable_value / tf.train.Saver (NetworkVP.py:62-64,267-288).
+ * which: 0 = weights, 1 = RMSProp `ms` slot, 2 = RMSProp `mom` slot, 3 = last gradient. */
+int ga3c_net_param_count(ga3c_net* net, int64_t* count);
+int ga3c_net_get_arena(ga3c_net* net, int32_t which, float* out, int64_t count);
+int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t count);
+int ga3c_net_get_step(ga3c_net* net, int64_t* step);        /* get_global_step, NetworkVP.py:233-235 */
+int ga3c_net_set_step(ga3c_net* net, int64_t step);
+
+/* predict_p_and_v (NetworkVP.py:248-252): x f32[B,84,84,4] NHWC host buffer ->
+ * p f32[B,A] (softmax_p), v f32[B] (logits_v); z f32[B,A] (logits_p) if not NULL. */
+int ga3c_net_predict(ga3c_net* net, const float* x, int32_t batch, float* p, float* v, float* z);
+/* Same, states shipped as the uint8 frames of Environment._preprocess before its
+ * `/128 - 1` (Environment.py:59-60); the conversion runs on the GPU, bit-identically. */
+int ga3c_net_predict_u8(ga3c_net* net, const uint8_t* x, int32_t batch, float* p, float* v, float* z);
+
+/* train (NetworkVP.py:254-257 = sess.run(train_op)): forward, loss, backward,
+ * (all-reduce when a communicator is attached), RMSProp, global_step += 1.
+ * y_r f32[B], a f32[B,A] one-hot.  losses (may be NULL) receives
+ * {cost_p_1_agg, cost_p_2_agg, cost_v} (NetworkVP_discrate.py:61,83-84) of this rank's rows. */
+int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch,
+                   float learning_rate, float beta, float* losses);
+/* The two halves of train, for tests and for callers that own the exchange step:
+ * gradients only (left in arena 3), then the optimizer step on arena 3. */
+int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, const float* a,
+                           int32_t batch, float beta, float* losses);
+int ga3c_net_apply_grads(ga3c_net* net, float learning_rate);
+
+/* Device-resident path (inputs already in HBM; what bench.py times).
+ * upload stages a batch into the train lane (y_r / a may be NULL for predict-only use). */
+int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch);
+int ga3c_net_predict_resident(ga3c_net* net, int32_t batch);   /* async on the train lane's stream */
+int ga3c_net_train_resident(ga3c_net* net, int32_t batch, float learning_rate, float beta);
+int ga3c_net_sync(ga3c_net* net);
+/* Runs `iters` back-to-back resident steps (mode 0 = predict, 1 = train) between two HIP
+ * events recorded on the stream the kernels run on; returns the elapsed milliseconds. */
+int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t iters,
+                           float learning_rate, float beta, float* elapsed_ms);
+/* Same bracket around ONE kernel of the step (name as in DESIGN.md, e.g. "conv1_fwd"). */
+int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32_t iters,
+                         float* elapsed_ms);
+
+/* Activations / per-sample gradients of the last resident or train-lane step, for parity tests:
+ * name in {"n1","n2","d1","z","p","v","dz","dv","dd1","dn2","dn1"}. */
+int ga3c_net_fetch(ga3c_net* net, const char* name, float* out, int64_t count);
+
+/* Pinned host memory for staging arrays (ThreadPredictor.py:46-47 `states`), so that
+ * predict/train copy by DMA without an intermediate host copy. */
+int ga3c_host_alloc(void** ptr, int64_t bytes);
+int ga3c_host_free(void* ptr);
+
+/* Data-parallel training over RCCL (no counterpart in the reference, which is
+ * single-device: Config.py:62).  id is an opaque 128-byte token made on rank 0 and
+ * handed to every rank by the launcher.  After comm_init, train and apply_grads
+ * all-reduce (sum) the gradient arena across ranks before the optimizer step. */
+#define GA3C_COMM_ID_BYTES 128
+int ga3c_comm_make_id(uint8_t id[GA3C_COMM_ID_BYTES]);
+int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int32_t rank, int32_t world);
+int ga3c_net_allreduce_grads(ga3c_net* net);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GA3C_ABI_H */

@@ -1,0 +1,96 @@
+/* ga3c_host.h -- C ABI of libga3c_host.so: host-only pieces of the GA3C hot path
+ * (no HIP; safe to load in forked agent processes).
+ *
+ *   returns     ProcessAgent._accumulate_rewards            (/root/reference/ga3c/ProcessAgent.py:69-84)
+ *   transport   prediction_q / wait_q / training_q          (Server.py:73-75, ProcessAgent.py:64,102-107,175,
+ *               of the reference, which are pickling            ThreadPredictor.py:45-66, ThreadTrainer.py:42-62)
+ *               multiprocessing.Queues
+ *
+ * All functions return 0 (or a non-negative count / id where stated) on success and a negative
+ * GA3C_H_E* code on failure.
+ */
+#ifndef GA3C_HOST_H
+#define GA3C_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA3C_H_OK 0
+#define GA3C_H_EINVAL (-1)
+#define GA3C_H_ESYS (-2)      /* shm_open / mmap / ftruncate failed (errno kept) */
+#define GA3C_H_ETIMEOUT (-3)  /* a blocking call timed out (not an error for pollers) */
+#define GA3C_H_ECLOSED (-4)   /* the transport was shut down */
+
+const char* ga3c_host_last_error(void);
+
+/* ---- returns --------------------------------------------------------------------------------
+ * Bit-exact restatement of ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84, call site
+ * :148-149): IEEE f64, sequential `reward_sum = gamma * reward_sum`, all T rows kept, row T-1
+ * keeps its raw reward; only (discounting && !use_intermediate_reward) writes anything back. */
+int ga3c_returns_fork(const double* rewards, int32_t T, double gamma, double terminal_reward,
+                      int32_t discounting, int32_t use_intermediate_reward, double* out);
+/* Upstream-GA3C n-step return (the lines the fork commented out, ProcessAgent.py:83,146):
+ * R = clip(r_t) + gamma R seeded with bootstrap_value; writes T-1 rows. */
+int ga3c_returns_nstep(const double* rewards, int32_t T, double gamma, double bootstrap_value,
+                       double rmin, double rmax, double* out);
+
+/* ---- shared-memory transport ----------------------------------------------------------------
+ * One POSIX shm segment holds
+ *   agent slots   [max_agents] x { state (state_bytes), p[f32 x num_actions], v, request/response words }
+ *   request ring  lock-free MPMC ring of agent ids (capacity >= max_agents: one request per agent in flight,
+ *                 as wait_q = Queue(maxsize=1) in ProcessAgent.py:64)
+ *   rollout slots [train_slots] x { rows, states[train_rows x state_bytes], returns f32[train_rows],
+ *                 actions i32[train_rows] }, with a free ring and a ready ring (the bound of
+ *                 Queue(maxsize=MAX_QUEUE_SIZE), Server.py:73)
+ * The whole segment can be registered with HIP (hipHostRegister) so the GPU gathers states
+ * straight from the slots.  Blocking uses futexes in the segment; nothing spins.            */
+typedef struct ga3c_shm ga3c_shm;
+
+typedef struct ga3c_shm_config {
+  int32_t max_agents;
+  int32_t num_actions;
+  int32_t state_bytes;   /* 28224 (uint8 frames) or 112896 (f32 states) */
+  int32_t train_slots;   /* rollouts in flight (MAX_QUEUE_SIZE) */
+  int32_t train_rows;    /* rows per rollout slot (TIME_MAX + 1) */
+  int32_t reserved[3];
+} ga3c_shm_config;
+
+int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out);  /* server, before agents start */
+int ga3c_shm_attach(const char* name, ga3c_shm** out);                              /* agent process */
+int ga3c_shm_close(ga3c_shm* shm, int32_t unlink_segment);
+int ga3c_shm_shutdown(ga3c_shm* shm);      /* wakes every waiter with GA3C_H_ECLOSED */
+void* ga3c_shm_base(ga3c_shm* shm);
+int64_t ga3c_shm_bytes(ga3c_shm* shm);
+int ga3c_shm_get_config(ga3c_shm* shm, ga3c_shm_config* cfg);
+int64_t ga3c_shm_state_offset(ga3c_shm* shm, int32_t agent);      /* byte offset of an agent's state in the segment */
+int64_t ga3c_shm_agent_stride(ga3c_shm* shm);
+int64_t ga3c_shm_rollout_offset(ga3c_shm* shm, int32_t slot);     /* byte offset of a rollout slot's states */
+int64_t ga3c_shm_rollout_stride(ga3c_shm* shm);
+
+/* agent side of predict (ProcessAgent.py:102-107) */
+void* ga3c_pq_state_ptr(ga3c_shm* shm, int32_t agent);
+int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
+int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
+/* predictor side (ThreadPredictor.py:50-55,61-63): block up to timeout for ONE request, then drain
+ * without waiting up to max_ids; returns the count (0 on timeout). */
+int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t timeout_ms);
+int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* p, const float* v);
+
+/* training queue: agent side (ProcessAgent.py:175), trainer side (ThreadTrainer.py:49-59) */
+int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms);                 /* -> free slot id */
+void* ga3c_tq_states(ga3c_shm* shm, int32_t slot);
+float* ga3c_tq_returns(ga3c_shm* shm, int32_t slot);
+int32_t* ga3c_tq_actions(ga3c_shm* shm, int32_t slot);
+int ga3c_tq_commit(ga3c_shm* shm, int32_t slot, int32_t rows);
+int ga3c_tq_pop(ga3c_shm* shm, int32_t timeout_ms);                     /* -> ready slot id */
+int ga3c_tq_rows(ga3c_shm* shm, int32_t slot);
+int ga3c_tq_release(ga3c_shm* shm, int32_t slot);
+int ga3c_tq_ready_count(ga3c_shm* shm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GA3C_HOST_H */

@@ -1,0 +1,174 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the oracle.
+
+Tolerances: BASELINE.json asks for policy/value within 1e-4 in fp32; gradients and the optimizer
+step are held to 1e-4 relative to the largest entry of each tensor (f32 summation order differs
+from the f64 oracle, nothing else does).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ga3c_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def nets():
+    import ga3c_amd  # noqa: F401  (puts the flat modules on sys.path)
+    from NetworkVP import Network
+    made = {}
+
+    def get(num_actions, max_batch=160):
+        key = (num_actions, max_batch)
+        if key not in made:
+            made[key] = Network("gpu:0", "test", num_actions, (84, 84, 4), max_batch=max_batch, predict_lanes=2)
+        return made[key]
+    yield get
+    for n in made.values():
+        n.close()
+
+
+def _oracle_params(net):
+    arena = net.get_arena(0).astype(np.float64)
+    out, off = {}, 0
+    for name in o.PARAM_ORDER:
+        shape = o.param_shapes(net.num_actions)[name]
+        size = int(np.prod(shape))
+        out[name] = arena[off:off + size].reshape(shape)
+        off += size
+    return out
+
+
+def _flat(d, num_actions):
+    return np.concatenate([np.asarray(d[k]).reshape(-1) for k in o.PARAM_ORDER])
+
+
+def _batch(bsz, num_actions, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xk = rng.integers(0, 256, size=(bsz, 84, 84, 4), dtype=np.uint8)
+    x = xk.astype(np.float32) / np.float32(128.0) - np.float32(1.0)
+    act = rng.integers(0, num_actions, size=bsz)
+    y = rng.uniform(-1, 1, size=bsz)
+    return xk, x, np.eye(num_actions, dtype=np.float32)[act], y
+
+
+def test_init_matches_oracle_init(nets):
+    net = nets(6)
+    want = _flat(o.init_params(6, seed=12345), 6)
+    got = net.get_arena(0)
+    assert got.shape == (1005623,)
+    assert np.array_equal(got, want.astype(np.float32))
+
+
+@pytest.mark.parametrize("num_actions,bsz", [(6, 1), (6, 5), (6, 37), (6, 128), (4, 19), (18, 33)])
+def test_forward_matches_oracle(nets, num_actions, bsz):
+    net = nets(num_actions)
+    _, x, _, _ = _batch(bsz, num_actions, 100 + bsz)
+    p, v, z = net.predict_p_v_logits(x)
+    ref = o.forward(_oracle_params(net), x.astype(np.float64))
+    assert np.max(np.abs(p - ref["p"])) < TOL
+    assert np.max(np.abs(v - ref["v"])) < TOL
+    assert np.max(np.abs(z - ref["z"])) < TOL
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_forward_golden_fixture(nets, golden_dir):
+    z = np.load(os.path.join(golden_dir, "nn_small.npz"))
+    for num_actions in (6, 4, 18):
+        net = nets(num_actions)
+        net.set_arena(0, _flat(o.init_params(num_actions), num_actions))
+        t = "A%d_" % num_actions
+        x = z[t + "x_u8"].astype(np.float32) / np.float32(128.0) - np.float32(1.0)
+        p, v, logits = net.predict_p_v_logits(x)
+        assert np.max(np.abs(p - z[t + "p"])) < TOL
+        assert np.max(np.abs(v - z[t + "v"])) < TOL
+        assert np.max(np.abs(logits - z[t + "z"])) < TOL
+
+
+def test_u8_path_is_bit_identical_to_f32_path(nets):
+    net = nets(6)
+    xk, x, _, _ = _batch(9, 6, 77)
+    p1, v1, z1 = net.predict_p_v_logits(x)
+    p2, v2, z2 = net.predict_p_v_logits(xk)
+    assert np.array_equal(p1, p2) and np.array_equal(v1, v2) and np.array_equal(z1, z2)
+
+
+def test_activations_match_oracle(nets):
+    net = nets(6)
+    _, x, a, y = _batch(7, 6, 5)
+    net.compute_grads(x, y, a)
+    ref = o.forward(_oracle_params(net), x.astype(np.float64), keep=True)
+    for name, want in (("n1", ref["n1"]), ("n2", ref["n2"]), ("d1", ref["d1"])):
+        got = net.fetch(name, want.size).reshape(want.shape)
+        assert np.max(np.abs(got - want)) < TOL, name
+
+
+@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 5, {}), (6, 37, {}), (6, 128, {}), (4, 16, {}), (18, 21, {})])
+def test_gradients_match_oracle(nets, num_actions, bsz, flags):
+    net = nets(num_actions)
+    _, x, a, y = _batch(bsz, num_actions, 300 + bsz)
+    net.beta = 0.01
+    losses = net.compute_grads(x, y, a)
+    params = _oracle_params(net)
+    ref_l, ref_g = o.loss_and_grads(params, x.astype(np.float64), y, a.astype(np.float64), 0.01)
+    want_l = np.array([ref_l["cost_p_1_agg"], ref_l["cost_p_2_agg"], ref_l["cost_v"]])
+    assert np.allclose(losses, want_l, rtol=1e-4, atol=1e-4)
+    for name, want in (("dz", ref_g["dz"]), ("dv", ref_g["dv"]), ("dd1", ref_g["dd1"]), ("dn2", ref_g["dn2"]),
+                       ("dn1", ref_g["dn1"])):
+        got = net.fetch(name, want.size).reshape(want.shape)
+        scale = max(np.max(np.abs(want)), 1e-6)
+        assert np.max(np.abs(got - want)) < TOL * max(scale, 1.0), name
+    got = net.get_arena(3)
+    off = 0
+    for name in o.PARAM_ORDER:
+        want = np.asarray(ref_g[name]).reshape(-1)
+        g = got[off:off + want.size]
+        off += want.size
+        scale = max(np.max(np.abs(want)), 1.0)
+        assert np.max(np.abs(g - want)) < TOL * scale, (name, np.max(np.abs(g - want)), scale)
+
+
+def test_train_step_matches_oracle_rmsprop(nets):
+    net = nets(6)
+    net.set_arena(0, _flat(o.init_params(6), 6))
+    net.set_arena(1, np.ones(net.param_count, np.float32))
+    _, x, a, y = _batch(24, 6, 9)
+    params = _oracle_params(net)
+    ms = {k: np.ones_like(v) for k, v in params.items()}
+    net.learning_rate, net.beta = 3e-4, 0.01
+    step0 = net.get_global_step()
+    for it in range(3):
+        net.train(x, y, a, None, None, 0)
+        o.train_step(params, ms, x.astype(np.float64), y, a.astype(np.float64), 3e-4, 0.01)
+    assert net.get_global_step() == step0 + 3
+    got, want = net.get_arena(0), _flat(params, 6)
+    assert np.max(np.abs(got - want)) < 1e-5
+    got_ms, want_ms = net.get_arena(1), _flat(ms, 6)
+    assert np.max(np.abs(got_ms - want_ms)) < 1e-5 * max(1.0, np.max(np.abs(want_ms)))
+    # the update is real: weights moved by about lr/sqrt(1.1) per nonzero gradient entry
+    assert np.max(np.abs(got - _flat(o.init_params(6), 6))) > 1e-4
+
+
+def test_train_is_reproducible_bit_for_bit(nets):
+    net = nets(6)
+    _, x, a, y = _batch(40, 6, 21)
+    outs = []
+    for _ in range(2):
+        net.set_arena(0, _flat(o.init_params(6), 6))
+        net.set_arena(1, np.ones(net.param_count, np.float32))
+        net.train(x, y, a, None, None, 0)
+        outs.append(net.get_arena(0))
+    assert np.array_equal(outs[0], outs[1])
+
+
+def test_bad_shapes_are_rejected(nets):
+    net = nets(6, 160)
+    _, x, a, y = _batch(2, 6, 1)
+    with pytest.raises(RuntimeError):
+        net.predict_p_and_v(np.zeros((161, 84, 84, 4), np.float32))
+    with pytest.raises(RuntimeError):
+        net.predict_p_and_v(np.zeros((0, 84, 84, 4), np.float32))
