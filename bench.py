@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric (predictions/s + training-steps/s, 84x84x4 stacked
+frames, NetworkVP) on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over one batch that is already resident in HBM:
+  predict leg (the headline `value`): one ThreadPredictor batch (BASELINE.json configs[1]:
+      batch = 128 states) through the HIP NetworkVP forward -> p, v;
+  train leg (reported under "train"): one ThreadTrainer batch (configs[2]: 128 rows) through forward,
+      loss, backward, RCCL all-reduce of the gradient arena when N > 1, RMSProp.
+Per-GPU work is fixed as N grows (weak scaling); predictions need no collective.
+torch is used here only as plumbing (process group for the barrier / max-over-ranks and the device
+sync); the product path is libga3c_hip.so via ctypes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FLOP_PER_PREDICTION = {4: 7_580_160, 6: 7_581_184, 18: 7_587_328}
+FLOP_CONV1_PER_SAMPLE = 3_612_672                                       # 441 * 256 * 16 * 2
+MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--actions", type=int, default=6)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length; 0 disables it")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        world, rank, local_rank = 1, 0, 0
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    from NetworkVP import Network
+    import _native as nat
+
+    B, A, K, W = args.batch, args.actions, args.steps, args.warmup
+    Config.PREDICTION_BATCH_SIZE = B
+    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=1)
+    lib, h = net._lib, net._h
+
+    if world > 1:
+        cid = torch.from_numpy(Network.make_comm_id() if rank == 0 else np.zeros(nat.COMM_ID_BYTES, np.uint8))
+        dist.broadcast(cid, src=0)
+        net.comm_init(cid.numpy(), rank, world)
+
+    # synthetic inputs of the reference's shape and value set
+    rng = np.random.Generator(np.random.PCG64(12345 + rank))
+    x = rng.integers(0, 256, size=(B, 84, 84, 4), dtype=np.uint8).astype(np.float32) / np.float32(128) - np.float32(1)
+    act = np.eye(A, dtype=np.float32)[rng.integers(0, A, B)]
+    y_r = rng.uniform(-1, 1, B).astype(np.float32)
+    nat.check(lib.ga3c_net_upload(h, nat.ptr(x), nat.ptr(y_r), nat.ptr(act), B), "upload")
+    lr, beta = float(Config.LEARNING_RATE_START), float(Config.BETA_START)
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(mode, steps):
+        ev_ms = nat.C.c_float()
+        barrier_sync()
+        t0 = time.perf_counter()
+        nat.check(lib.ga3c_net_time_resident(h, mode, B, steps, lr, beta, nat.C.byref(ev_ms)), "time_resident")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if world > 1:
+            dist.barrier()
+            tmax = torch.tensor([t1 - t0], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax[0]), ev_ms.value
+        return t1 - t0, ev_ms.value
+
+    ev_ms = nat.C.c_float()
+    for mode in (0, 1):
+        if W > 0:
+            nat.check(lib.ga3c_net_time_resident(h, mode, B, W, lr, beta, nat.C.byref(ev_ms)), "warmup")
+    pred_s, pred_ev_ms = timed(0, K)
+    train_s, train_ev_ms = timed(1, K)
+
+    out = None
+    if rank == 0:
+        pps = world * K * B / pred_s
+        tps = K / train_s                       # synchronous data-parallel: one global step per K
+        out = {
+            "metric": "predictions_per_sec", "value": pps, "unit": "predictions/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": pred_s / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PongDeterministic-v4 84x84x4 stacked frames, NetworkVP forward, "
+                                   "predictor batch=%d per GPU, A=%d (BASELINE configs[1])" % (B, A),
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "inputs": "resident in HBM (f32 NHWC), outputs p,v left in HBM"},
+            "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
+                      "ms_per_step": train_s / K * 1e3, "rows_per_step": world * B,
+                      "trained_samples_per_sec": world * K * B / train_s,
+                      "workload": "forward+loss+backward%s+RMSProp, %d rows per GPU (BASELINE configs[2])"
+                                  % ("+RCCL all-reduce(sum) of 4.02 MB grads" if world > 1 else "", B)},
+            "stream_ms_per_step": {"predict": pred_ev_ms / K, "train": train_ev_ms / K},
+        }
+
+    # ---- roofline of the dominant kernel (conv1 forward: 48% of the forward FLOPs), rank 0 only
+    if rank == 0:
+        kernels = {}
+        iters = 50
+        for name in ("conv1_fwd", "conv2_fwd", "dense1_fwd", "dense1_dw", "dense1_dx", "conv2_dw", "conv2_dx",
+                     "conv1_dw", "rmsprop"):
+            nat.check(lib.ga3c_net_time_kernel(h, name.encode(), B, 5, nat.C.byref(ev_ms)), name)
+            nat.check(lib.ga3c_net_time_kernel(h, name.encode(), B, iters, nat.C.byref(ev_ms)), name)
+            kernels[name] = ev_ms.value / iters * 1e3          # microseconds per launch
+        t_conv1 = kernels["conv1_fwd"] * 1e-6
+        achieved = FLOP_CONV1_PER_SAMPLE * B / t_conv1 / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("conv1_fwd_B%d" % B)
+        out["roofline"] = {"kernel": "conv1_fwd_kernel", "bound": "mfma", "achieved": achieved,
+                           "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                           "traffic": traffic, "avg_launch_us": kernels["conv1_fwd"],
+                           "algorithmic_flop_per_launch": FLOP_CONV1_PER_SAMPLE * B}
+        out["kernel_us"] = kernels
+        flop = FLOP_PER_PREDICTION.get(A, 7_581_184)
+        out["end_to_end_mfma_frac"] = out["value"] * flop / (world * MFMA_F32_PEAK_TFLOPS * 1e12)
+
+    # ---- CPU baseline: the oracle's C port on this box's host cores (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        import ga3c_oracle_cport as oc
+        theta = net.get_arena(0)
+        oc.predict(theta, A, x)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            oc.predict(theta, A, x)
+            n += 1
+        dt = time.perf_counter() - t0
+        ms = np.ones_like(theta)
+        th2 = theta.copy()
+        oc.train(th2, ms, A, x, y_r, act, lr, beta)
+        m, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            oc.train(th2, ms, A, x, y_r, act, lr, beta)
+            m += 1
+        dt2 = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": n * B / dt, "unit": "predictions/s", "cores": oc.threads(), "kind": "port",
+                               "sample": "%d forward passes of the same %d-state batch (%.1f s) by oracle/ga3c_oracle_c.c, "
+                                         "OpenMP over %d threads of %d host cores" % (n, B, dt, oc.threads(), os.cpu_count()),
+                               "train_steps_per_sec": m / dt2}
+
+    net.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

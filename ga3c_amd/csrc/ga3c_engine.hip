@@ -8,6 +8,7 @@
 //   per lane   x[B,84,84,4]  n1[B,21,21,16]  n2[B,11,11,32]  part[KS,B,256]  d1[B,256]  z,p[B,A]  v[B]
 //   train lane additionally  y_r, a, dz, dv, lossrow[B,3], dd1[B,256], dn2, dn1, slab2, slab1.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
@@ -681,57 +682,66 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
 }
 
 int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32_t iters, float* elapsed_ms) {
+  // Each launch carries its own start/stop events (hipExtLaunchKernelGGL), so the sum is pure kernel
+  // execution time on the train lane's stream, without launch gaps.  Buffers hold whatever the last
+  // step left there; "rmsprop" runs with lr = 0 but does advance the `ms` slot (use a scratch net).
   if (!net || !kernel || !elapsed_ms) return fail(GA3C_EINVAL, "null argument");
   if (iters < 1 || batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "bad batch/iters");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
   TrainLane& t = net->tr;
   const float* th = net->theta[net->cur];
+  float* g = net->grad;
   const int B = batch;
   const std::string k(kernel);
-  HIPCHK(hipEventRecord(t.ev0, t.st));
+  HIPCHK(hipStreamSynchronize(t.st));
+  double total = 0.0;
+#define TL(kern, grid, ...) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, t.st, t.ev0, t.ev1, 0, __VA_ARGS__)
   for (int i = 0; i < iters; ++i) {
     if (k == "conv1_fwd") {
       const int M = B * P1, nt = (M + 15) / 16;
       int blocks = (nt + 3) / 4;
       if (blocks > 512) blocks = 512;
-      hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, t.st, t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, M, nt);
+      TL(conv1_fwd_kernel, dim3(blocks), t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, M, nt);
     } else if (k == "conv2_fwd") {
       const int M = B * P2, nt = (M + 15) / 16;
       int blocks = (nt + 3) / 4;
       if (blocks > 512) blocks = 512;
-      hipLaunchKernelGGL(conv2_fwd_kernel, dim3(blocks), dim3(256), 0, t.st, t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, M, nt);
+      TL(conv2_fwd_kernel, dim3(blocks), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, M, nt);
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
-      hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 15) / 16, ks), dim3(256), 0, t.st, t.f.n2, th + OFF_WD, t.f.part,
-                         B, KSTEPS_DENSE / ks);
+      TL(dense1_fwd_kernel, dim3((B + 15) / 16, ks), t.f.n2, th + OFF_WD, t.f.part, B, KSTEPS_DENSE / ks);
     } else if (k == "conv1_dw") {
       const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
-      hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch), dim3(256), 0, t.st, t.f.x, t.dn1, t.slab1, P, ch);
+      TL(conv1_dw_kernel, dim3(nch), t.f.x, t.dn1, t.slab1, P, ch);
     } else if (k == "conv2_dw") {
       const int P = B * P2, ch = chunk2(B), nch = (P + ch - 1) / ch;
-      hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch, 2), dim3(256), 0, t.st, t.f.n1, t.dn2, t.slab2, P, ch);
+      TL(conv2_dw_kernel, dim3(nch, 2), t.f.n1, t.dn2, t.slab2, P, ch);
     } else if (k == "conv2_dx") {
       const int nt = (B * P2 + 15) / 16;
       int blocks = (nt + 3) / 4;
       if (blocks > 256) blocks = 256;
-      hipLaunchKernelGGL(conv2_dx_kernel, dim3(blocks, 4), dim3(256), 0, t.st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+      TL(conv2_dx_kernel, dim3(blocks, 4), t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
     } else if (k == "dense1_dw") {
-      hipLaunchKernelGGL(dense1_dw_kernel, dim3(FLAT / 32, 2), dim3(256), 0, t.st, t.f.n2, t.dd1, net->grad + OFF_WD,
-                         net->grad + OFF_BD, B);
+      TL(dense1_dw_kernel, dim3(FLAT / 32, 2), t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD, B);
     } else if (k == "dense1_dx") {
-      hipLaunchKernelGGL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), dim3(256), 0, t.st, t.dd1,
-                         th + OFF_WD, t.f.n2, t.dn2, B);
+      TL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), t.dd1, th + OFF_WD, t.f.n2, t.dn2, B);
     } else if (k == "rmsprop") {
-      CHK(launch_rmsprop(net, net->theta[net->cur], net->theta[net->cur], 0.0f, t.st));
+      int blocks = (int)((net->n + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->cur], net->ms, net->mom, net->grad, net->n,
+         0.0f, 1.0f - net->cfg.rmsprop_decay, 0.0f, net->cfg.rmsprop_epsilon, net->tt, t.scales);
     } else {
       return fail(GA3C_EINVAL, "unknown kernel '%s'", kernel);
     }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(t.ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, t.ev0, t.ev1));
+    total += ms;
   }
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(t.ev1, t.st));
-  HIPCHK(hipEventSynchronize(t.ev1));
-  HIPCHK(hipEventElapsedTime(elapsed_ms, t.ev0, t.ev1));
+#undef TL
+  *elapsed_ms = (float)total;
   return GA3C_OK;
 }
 
