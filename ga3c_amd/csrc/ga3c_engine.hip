@@ -185,12 +185,12 @@ int launch_forward(ga3c_net* net, const Fwd& f, const float* th, int B, hipStrea
   h.d1 = f.d1; h.z = f.z; h.p = f.p; h.v = f.v;
   h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
   h.log_softmax = (net->cfg.flags & GA3C_FLAG_LOG_SOFTMAX) ? 1 : 0;
-  if (train) {
-    h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.beta = beta;
-    hipLaunchKernelGGL(heads_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, st, h);
-  } else {
-    hipLaunchKernelGGL(heads_kernel<false>, dim3((B + 3) / 4), dim3(256), 0, st, h);
-  }
+  if (train) { h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.beta = beta; }
+#define HEADS(T, AM) hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + 3) / 4), dim3(256), 0, st, h)
+  if (A <= 8) { if (train) HEADS(true, 8); else HEADS(false, 8); }
+  else if (A <= 24) { if (train) HEADS(true, 24); else HEADS(false, 24); }
+  else { if (train) HEADS(true, 64); else HEADS(false, 64); }
+#undef HEADS
   HIPCHK(hipGetLastError());
   return GA3C_OK;
 }
@@ -211,7 +211,7 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   {
     const int P = B * P2, ch = chunk2(B), nch = (P + ch - 1) / ch;
     hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch, 2), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, P, ch);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB2 + 255) / 256), dim3(256), 0, st, t.slab2, nch, SLAB2, 256 * 32,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB2 + 63) / 64), dim3(1024), 0, st, t.slab2, nch, SLAB2, 256 * 32,
                        g + OFF_W2, g + OFF_B2);
   }
   {
@@ -223,7 +223,7 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   {
     const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
     hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, P, ch);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB1 + 255) / 256), dim3(256), 0, st, t.slab1, nch, SLAB1, 256 * 16,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB1 + 63) / 64), dim3(1024), 0, st, t.slab1, nch, SLAB1, 256 * 16,
                        g + OFF_W1, g + OFF_B1);
   }
   HIPCHK(hipGetLastError());

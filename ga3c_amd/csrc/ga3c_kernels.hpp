@@ -211,25 +211,47 @@ struct HeadArgs {
   float beta, log_eps, min_policy; int log_softmax;
 };
 
-template <bool TRAIN>
+template <bool TRAIN, int AMAX>
 __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= h.B) return;   // wave-uniform
+  // this lane's 4 hidden units x A policy weights are 4*A contiguous floats: issue every load up front
+  float wreg[4][AMAX];
+  const float* wp = h.wp + (size_t)(4 * lane) * h.A;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int o = 0; o < AMAX; ++o) wreg[q][o] = o < h.A ? wp[q * h.A + o] : 0.f;
+  const f32x4 wv4 = ld4(h.wv + 4 * lane);
   f32x4 d = ld4(h.bd + 4 * lane);
-  for (int ks = 0; ks < h.ks; ++ks) d += ld4(h.part + ((size_t)ks * h.B + b) * HID + 4 * lane);
+  const float* pp = h.part + (size_t)b * HID + 4 * lane;
+  const size_t kstride = (size_t)h.B * HID;
+  int ks = 0;
+  for (; ks + 11 <= h.ks; ks += 11) {   // dense_ks() picks 22, 11 or 2 slices: keep 11 loads in flight
+    f32x4 t[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) t[i] = ld4(pp + (size_t)(ks + i) * kstride);
+#pragma unroll
+    for (int i = 0; i < 11; ++i) d += t[i];
+  }
+  for (; ks < h.ks; ++ks) d += ld4(pp + (size_t)ks * kstride);
 #pragma unroll
   for (int q = 0; q < 4; ++q) d[q] = fmaxf(d[q], 0.f);
   *reinterpret_cast<f32x4*>(h.d1 + (size_t)b * HID + 4 * lane) = d;
 
-  const f32x4 wv4 = ld4(h.wv + 4 * lane);
   const float v = wave_sum(d[0] * wv4[0] + d[1] * wv4[1] + d[2] * wv4[2] + d[3] * wv4[3]) + h.bv[0];
+  float zpart[AMAX];
+#pragma unroll
+  for (int o = 0; o < AMAX; ++o) zpart[o] = d[0] * wreg[0][o] + d[1] * wreg[1][o] + d[2] * wreg[2][o] + d[3] * wreg[3][o];
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1)
+#pragma unroll
+    for (int o = 0; o < AMAX; ++o) zpart[o] += __shfl_xor(zpart[o], sh, 64);
   float zmine = -INFINITY;
-  for (int o = 0; o < h.A; ++o) {
-    const float* wp = h.wp + (size_t)(4 * lane) * h.A + o;
-    const float tot = wave_sum(d[0] * wp[0] + d[1] * wp[h.A] + d[2] * wp[2 * h.A] + d[3] * wp[3 * h.A]);
-    if (lane == o) zmine = tot + h.bp[o];
-  }
+#pragma unroll
+  for (int o = 0; o < AMAX; ++o)
+    if (lane == o && o < h.A) zmine = zpart[o] + h.bp[o];
   const bool mine = lane < h.A;
   const float zmax = wave_max(zmine);
   const float e = mine ? expf(zmine - zmax) : 0.f;
@@ -304,21 +326,39 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadBwdArgs h) {
     for (int o = 0; o < h.A; ++o) acc += h.dz[(size_t)b * h.A + o] * h.wp[(size_t)k * h.A + o];
     h.dd1[(size_t)b * HID + k] = h.d1[(size_t)b * HID + k] > 0.f ? acc : 0.f;
   } else if (blk <= h.B + h.A) {
+    // thread = (4 hidden units kq, batch residue bg): float4 rows of d1, partial sums folded through LDS
     const int o = blk - h.B;
     const bool isv = o == h.A;
-    float acc = 0.f, bsum = 0.f;
-    for (int b = 0; b < h.B; ++b) {
-      const float gh = isv ? h.dv[b] : h.dz[(size_t)b * h.A + o];
-      acc += h.d1[(size_t)b * HID + k] * gh;
+    const int kq = k & 63, bg = k >> 6;
+    f32x4 acc = zero4();
+    float bsum = 0.f;
+    for (int b0 = bg; b0 < h.B; b0 += 32) {
+      f32x4 dd[8];
+      float gh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = b0 + 4 * i;
+        const bool ok = b < h.B;
+        dd[i] = ok ? ld4(h.d1 + (size_t)b * HID + 4 * kq) : zero4();
+        gh[i] = ok ? (isv ? h.dv[b] : h.dz[(size_t)b * h.A + o]) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += dd[i] * gh[i];
     }
     for (int b = k; b < h.B; b += 256) bsum += isv ? h.dv[b] : h.dz[(size_t)b * h.A + o];
-    bsum = block_sum_256(bsum, sh);
-    if (isv) {
-      h.g_wv[k] = acc;
-      if (k == 0) h.g_bv[0] = bsum;
-    } else {
-      h.g_wp[(size_t)k * h.A + o] = acc;
-      if (k == 0) h.g_bp[o] = bsum;
+    __shared__ f32x4 sacc[4][64];
+    sacc[bg][kq] = acc;
+    bsum = block_sum_256(bsum, sh);   // contains the barriers that also publish sacc
+    if (bg == 0) {
+      const f32x4 tot = (sacc[0][kq] + sacc[1][kq]) + (sacc[2][kq] + sacc[3][kq]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (isv) h.g_wv[4 * kq + q] = tot[q];
+        else h.g_wp[(size_t)(4 * kq + q) * h.A + o] = tot[q];
+      }
+    }
+    if (k == 0) {
+      if (isv) h.g_bv[0] = bsum; else h.g_bp[o] = bsum;
     }
   } else {
     for (int c = 0; c < 3; ++c) {
@@ -592,22 +632,34 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ slab reduce (fixed order => reproducible)
-// out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e]
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int nchunks, int stride,
-                                                          int nw, float* __restrict__ out_w, float* __restrict__ out_b) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= stride) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = 0;
-  for (; c + 4 <= nchunks; c += 4) {
-    s0 += part[(size_t)c * stride + e];
-    s1 += part[(size_t)(c + 1) * stride + e];
-    s2 += part[(size_t)(c + 2) * stride + e];
-    s3 += part[(size_t)(c + 3) * stride + e];
+// out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e].
+// Block = 16 waves on the same 64 columns; wave w folds chunks w, w+16, ... (8 loads in flight),
+// then wave 0 adds the 16 partial rows in order.
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ part, int nchunks, int stride,
+                                                           int nw, float* __restrict__ out_w, float* __restrict__ out_b) {
+  __shared__ float sh[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const bool ok = e < stride;
+  float s0 = 0.f, s1 = 0.f;
+  for (int c0 = w; c0 < nchunks; c0 += 128) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + 16 * i;
+      t[i] = (ok && c < nchunks) ? part[(size_t)c * stride + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) { s0 += t[i]; s1 += t[i + 1]; }
   }
-  for (; c < nchunks; ++c) s0 += part[(size_t)c * stride + e];
-  const float tot = (s0 + s1) + (s2 + s3);
-  if (e < nw) out_w[e] = tot; else out_b[e - nw] = tot;
+  sh[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && ok) {
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += sh[i][lane];
+    if (e < nw) out_w[e] = tot; else out_b[e - nw] = tot;
+  }
 }
 
 // ------------------------------------------------------------------ gradient clipping (optional)
