@@ -1,0 +1,28 @@
+"""Entry point: `python GA3C.py KEY=VALUE ...` sets Config attributes, coerced to the type of the
+current value, then runs the server (reference: ga3c/GA3C.py:38-59).  As there, a bool can only be
+switched off with an empty value (`KEY=`), because bool("False") is True.
+"""
+import sys
+
+import _native  # noqa: F401  (fail early if the libraries are not built)
+from Config import Config
+
+
+def apply_argv(argv):
+    for arg in argv:
+        key, value = arg.split('=', 1)
+        setattr(Config, key, type(getattr(Config, key))(value))
+    if Config.PLAY_MODE:
+        Config.AGENTS = 1
+        Config.PREDICTORS = 1
+        Config.TRAINERS = 1
+        Config.DYNAMIC_SETTINGS = False
+        Config.LOAD_CHECKPOINT = True
+        Config.TRAIN_MODELS = False
+        Config.SAVE_MODELS = False
+
+
+if __name__ == '__main__':
+    apply_argv(sys.argv[1:])
+    from Server import Server
+    Server().main()

@@ -93,13 +93,23 @@ class Network:
             off += size
         assert off == self.param_count
         self.set_arena(0, initial_arena(self.num_actions, Config.RANDOM_SEED))
+        self._pinned = []
         self._log_lock = threading.Lock()
         self.last_losses = None
+
+    def pinned_array(self, shape, dtype=np.float32):
+        """Host staging array in HIP-pinned memory (freed by close()); predict/train DMA straight from it."""
+        arr, p = nat.pinned_array(shape, dtype)
+        self._pinned.append(p)
+        return arr
 
     def close(self):
         if getattr(self, "_h", None):
             self._lib.ga3c_net_destroy(self._h)
             self._h = None
+            for p in self._pinned:
+                nat.free_pinned(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -173,13 +183,19 @@ class Network:
     # ---- training ----------------------------------------------------------------------------
     def train(self, x, y_r, a, x2=None, done=None, trainer_id=0):
         """x2, done and trainer_id are accepted and ignored, as in NetworkVP.py:254-257."""
-        x = nat.as_f32(x)
         y = nat.as_f32(y_r)             # arrives as float64 (ProcessAgent.py:99); cast at the boundary
         a = nat.as_f32(a)
         losses = np.empty(3, dtype=np.float32)
-        nat.check(self._lib.ga3c_net_train(self._h, nat.ptr(x), nat.ptr(y), nat.ptr(a), int(x.shape[0]),
-                                           float(self.learning_rate), float(self.beta), nat.ptr(losses)),
-                  "ga3c_net_train")
+        if x.dtype == np.uint8:
+            x = np.ascontiguousarray(x)
+            nat.check(self._lib.ga3c_net_train_u8(self._h, nat.ptr(x, nat.u8p), nat.ptr(y), nat.ptr(a),
+                                                  int(x.shape[0]), float(self.learning_rate), float(self.beta),
+                                                  nat.ptr(losses)), "ga3c_net_train_u8")
+        else:
+            x = nat.as_f32(x)
+            nat.check(self._lib.ga3c_net_train(self._h, nat.ptr(x), nat.ptr(y), nat.ptr(a), int(x.shape[0]),
+                                               float(self.learning_rate), float(self.beta), nat.ptr(losses)),
+                      "ga3c_net_train")
         self.last_losses = losses
 
     def compute_grads(self, x, y_r, a):

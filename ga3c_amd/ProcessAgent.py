@@ -1,0 +1,162 @@
+"""Actor process: environment loop, predict() round trip, action sampling, rollout cut, returns,
+hand-off to the trainer.  Behaviour follows the reference's ProcessAgent
+(/root/reference/ga3c/ProcessAgent.py:44-178); the three pickling queues it talks to are replaced by
+the shared-memory transport (Transport.py / include/ga3c_host.h):
+
+  predict()            :102-107  state -> own slot, id -> request ring, sleep on the slot's futex
+  _accumulate_rewards  :69-84    bit-exact, computed by ga3c_returns_fork (f64, sequential products)
+  rollout cut          :145      on done or time_count == TIME_MAX; last experience re-used (:159)
+  run()                :164-178  rollout -> training slot; episode totals -> episode_log_q
+
+The debug prints of :131,133,152 are not reproduced; x2_/done_ stay in
+convert_data's signature but are not transported (Q10).
+"""
+import multiprocessing as mp
+import time
+from datetime import datetime
+
+import numpy as np
+
+from Config import Config
+from Environment import Environment, u8_to_f32
+from Experience import Experience
+import Transport as tp
+
+MP = mp.get_context("forkserver")     # children never inherit the server's HIP state
+
+
+def config_snapshot():
+    return {k: v for k, v in vars(Config).items() if k.isupper()}
+
+
+class ProcessAgent(MP.Process):
+    def __init__(self, id, transport_name, episode_log_q, config=None):
+        super(ProcessAgent, self).__init__()
+        self.id = id
+        self.transport_name = transport_name
+        self.episode_log_q = episode_log_q
+        self.config = config if config is not None else config_snapshot()
+        self.discount_factor = self.config["DISCOUNT"]
+        self.exit_flag = MP.Value('i', 0)
+        self.time_count = 0
+        self.transport = None
+        self.env = None
+
+    # ---- pieces with the reference's names and semantics ------------------------------------
+    @staticmethod
+    def _accumulate_rewards(experiences, discount_factor, terminal_reward):
+        if Config.RETURN_MODE == 'nstep':
+            # upstream GA3C: R = clip(r) + gamma R from the bootstrap value, last row dropped
+            out = tp.returns_nstep([e.reward for e in experiences], discount_factor, terminal_reward,
+                                   Config.REWARD_MIN, Config.REWARD_MAX)
+            for e, r in zip(experiences, out):
+                e.reward = float(r)
+            return experiences[:-1]
+        out = tp.accumulate_rewards_fork([e.reward for e in experiences], discount_factor, terminal_reward,
+                                         Config.DISCOUNTING, Config.USE_INTERMEDIATE_REWARD)
+        for e, r in zip(experiences, out):
+            e.reward = float(r)
+        return experiences                      # all T rows (ProcessAgent.py:84)
+
+    def convert_data(self, experiences):
+        x_ = np.array([u8_to_f32(e.state) if e.state.dtype == np.uint8 else e.state for e in experiences])
+        x2_ = np.array([u8_to_f32(e.next_state) if e.next_state.dtype == np.uint8 else e.next_state
+                        for e in experiences])
+        done_ = np.array([e.done for e in experiences])
+        a_ = np.eye(self.num_actions)[np.array([e.action for e in experiences])].astype(np.float32)
+        r_ = np.array([e.reward for e in experiences])
+        return x_, r_, a_, x2_, done_
+
+    def predict(self, state):
+        """state: uint8 [84,84,4] frames (STATE_TRANSPORT='u8') or f32 [84,84,4]."""
+        slot = self.transport.state_view(self.id, state.dtype)
+        slot[:] = state.reshape(-1)
+        self.transport.submit(self.id)
+        while True:
+            rc, p, v = self.transport.wait(self.id, Config.QUEUE_TIMEOUT_MS)
+            if rc == 0:
+                return p, v
+            if rc == tp.CLOSED or self.exit_flag.value:
+                raise SystemExit(0)
+
+    @staticmethod
+    def select_action(actions, prediction):
+        if Config.PLAY_MODE:
+            return int(np.argmax(prediction))
+        return int(np.random.choice(actions, p=prediction))
+
+    # ---- episode loop ------------------------------------------------------------------------
+    def run_episode(self):
+        self.env.reset()
+        done = False
+        experiences = []
+        self.time_count = 0
+        reward_sum = 0.0
+        as_u8 = Config.STATE_TRANSPORT == 'u8'
+        while not done:
+            if self.env.current_u8 is None:
+                self.env.step(None)             # frame queue still filling (ProcessAgent.py:127-129)
+                continue
+            state = self.env.current_u8 if as_u8 else self.env.current_state
+            prediction, value = self.predict(state)
+            action = self.select_action(self.actions, prediction)
+            reward, done = self.env.step(action)
+            reward_sum += reward
+            next_state = self.env.current_u8 if as_u8 else self.env.current_state
+            experiences.append(Experience(state, action, prediction, reward, next_state, done))
+            if done or self.time_count == Config.TIME_MAX:
+                if Config.RETURN_MODE == 'nstep':
+                    terminal_reward = 0.0 if done else float(value)
+                else:
+                    terminal_reward = reward    # the fork's choice (ProcessAgent.py:148)
+                updated = ProcessAgent._accumulate_rewards(experiences, self.discount_factor, terminal_reward)
+                yield updated, reward_sum
+                self.time_count = 0
+                experiences = [experiences[-1]]
+                reward_sum = 0.0
+            self.time_count += 1
+
+    def _ship(self, experiences):
+        """Rollout -> one slot of the training queue (stands for training_q.put, ProcessAgent.py:175)."""
+        while True:
+            slot = self.transport.acquire(Config.QUEUE_TIMEOUT_MS)
+            if slot >= 0:
+                break
+            if slot == tp.CLOSED or self.exit_flag.value:
+                raise SystemExit(0)
+        states, returns, actions = self.transport.rollout_views(slot)
+        n = len(experiences)
+        for i, e in enumerate(experiences):
+            states[i] = e.state.reshape(-1).view(np.uint8)
+            returns[i] = e.reward               # f64 -> f32 here, as TF's feed does (NetworkVP.py:70,256)
+            actions[i] = e.action
+        self.transport.commit(slot, n)
+
+    def run(self):
+        for k, v in self.config.items():
+            setattr(Config, k, v)
+        self.transport = tp.Transport.attach(self.transport_name)
+        self.env = Environment(self.id)
+        self.num_actions = self.env.get_num_actions()
+        self.actions = np.arange(self.num_actions)
+        time.sleep(np.random.rand() * 0.2)                              # staggered start (:167)
+        np.random.seed(np.int32(time.time() % 1 * 1000 + self.id * 10))  # (:168)
+        try:
+            while self.exit_flag.value == 0:
+                total_reward = 0
+                total_length = 0
+                finished = True
+                for experiences, reward_sum in self.run_episode():
+                    total_reward += reward_sum
+                    total_length += len(experiences) + 1        # frame accounting of :174
+                    if experiences:
+                        self._ship(experiences)
+                    if self.exit_flag.value and not (experiences and experiences[-1].done):
+                        finished = False                        # asked to stop mid-episode: log nothing
+                        break
+                if finished:
+                    self.episode_log_q.put((datetime.now(), total_reward, total_length))
+        except SystemExit:
+            pass
+        finally:
+            self.transport.close()

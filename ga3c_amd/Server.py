@@ -1,0 +1,139 @@
+"""Orchestrator: owns the transport, the model and the worker lists; counts train steps; anneals
+learning rate and beta; services checkpoint requests (reference: ga3c/Server.py:69-206).
+
+What changed against the reference, and why:
+  * prediction_q / training_q / wait_q are one shared-memory Transport (Transport.py) created
+    before any agent starts;
+  * the model is the HIP-backed Network (NetworkVP.py), selected where the reference selects its
+    TensorFlow class (Server.py:48-54);
+  * agents are started from a forkserver, so they never inherit the server's HIP state.
+"""
+import time
+
+from Config import Config
+from Environment import Environment
+from NetworkVP import Network
+from ProcessAgent import ProcessAgent, config_snapshot
+from ProcessStats import ProcessStats
+from ThreadDynamicAdjustment import ThreadDynamicAdjustment
+from ThreadPredictor import ThreadPredictor
+from ThreadTrainer import ThreadTrainer
+import Transport as tp
+
+
+class Server:
+    def __init__(self, model=None, max_agents=None):
+        self.stats = ProcessStats()
+        self.state_dim = self.get_state_dim()
+        self.num_actions = self.get_num_action()
+        self.max_agents = int(max_agents or max(2 * Config.AGENTS, Config.AGENTS + 16))
+        n_state = Config.IMAGE_HEIGHT * Config.IMAGE_WIDTH * Config.STACKED_FRAMES
+        state_bytes = n_state if Config.STATE_TRANSPORT == 'u8' else 4 * n_state
+        self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
+                                             Config.MAX_QUEUE_SIZE, Config.TIME_MAX + 1)
+        self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
+                                                             self.state_dim)
+        if Config.LOAD_CHECKPOINT:
+            try:
+                self.stats.episode_count.value = self.model.load()
+            except (OSError, KeyError, ValueError) as e:
+                print("checkpoint not loaded: %s" % e)
+        self.training_step = 0
+        self.frame_counter = 0
+        self.predictions_served = 0
+        self.agents = []
+        self.agent_id = 0
+        self.predictors = []
+        self.trainers = []
+        self.dynamic_adjustment = ThreadDynamicAdjustment(self)
+        print("Server initialized")
+
+    # ---- worker lifecycle (Server.py:106-139) ---------------------------------------------------
+    def add_agent(self):
+        if self.agent_id >= self.max_agents:
+            return
+        self.agents.append(ProcessAgent(self.agent_id, self.transport.name, self.stats.episode_log_q, config_snapshot()))
+        self.agents[-1].start()
+        self.agent_id += 1
+
+    def remove_agent(self):
+        self.agents[-1].exit_flag.value = True
+        self.agents[-1].join(5)
+        if self.agents[-1].is_alive():
+            self.agents[-1].terminate()
+        self.agents.pop()
+
+    def add_predictor(self):
+        self.predictors.append(ThreadPredictor(self, len(self.predictors), self.state_dim, self.transport))
+        self.predictors[-1].start()
+
+    def remove_predictor(self):
+        self.predictors[-1].exit_flag = True
+        self.predictors[-1].join()
+        self.predictors.pop()
+
+    def add_trainer(self):
+        self.trainers.append(ThreadTrainer(self, len(self.trainers)))
+        self.trainers[-1].start()
+
+    def remove_trainer(self):
+        self.trainers[-1].exit_flag = True
+        self.trainers[-1].join()
+        self.trainers.pop()
+
+    # ---- training bookkeeping (Server.py:141-153) ----------------------------------------------
+    def train_model(self, x_, r_, a_, x2, done, trainer_id):
+        self.model.train(x_, r_, a_, x2, done, trainer_id)
+        self.training_step += 1
+        self.frame_counter += x_.shape[0]
+        self.stats.training_count.value += 1
+        self.dynamic_adjustment.temporal_training_count += 1
+        if Config.TENSORBOARD and self.stats.training_count.value % Config.TENSORBOARD_UPDATE_FREQUENCY == 0:
+            self.model.log(x_, r_, a_, self.training_step)
+
+    def save_model(self):
+        self.model.save(self.stats.episode_count.value)
+
+    # ---- main loop (Server.py:155-198) ----------------------------------------------------------
+    def main(self, max_seconds=None):
+        self.stats.start()
+        self.dynamic_adjustment.start()
+        lr_mult = (Config.LEARNING_RATE_END - Config.LEARNING_RATE_START) / Config.ANNEALING_EPISODE_COUNT
+        beta_mult = (Config.BETA_END - Config.BETA_START) / Config.ANNEALING_EPISODE_COUNT
+        t0 = time.time()
+        try:
+            while self.stats.episode_count.value < Config.EPISODES:
+                step = min(self.stats.episode_count.value, Config.ANNEALING_EPISODE_COUNT - 1)
+                self.model.learning_rate = Config.LEARNING_RATE_START + lr_mult * step
+                self.model.beta = Config.BETA_START + beta_mult * step
+                if Config.SAVE_MODELS and self.stats.should_save_model.value > 0:
+                    self.save_model()
+                    self.stats.should_save_model.value = 0
+                if max_seconds is not None and time.time() - t0 > max_seconds:
+                    break
+                time.sleep(0.01)
+        finally:
+            self.shutdown()
+
+    def shutdown(self):
+        self.dynamic_adjustment.exit_flag = True
+        for a in self.agents:
+            a.exit_flag.value = True
+        self.transport.shutdown()
+        while self.agents:
+            self.remove_agent()
+        while self.predictors:
+            self.remove_predictor()
+        while self.trainers:
+            self.remove_trainer()
+        if self.stats.is_alive():
+            self.stats.terminate()
+        self.transport.close()
+
+    @staticmethod
+    def get_state_dim():
+        return Environment.get_state_dim()
+
+    @staticmethod
+    def get_num_action():
+        return int(Config.NUM_ACTIONS)

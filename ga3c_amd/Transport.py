@@ -1,0 +1,137 @@
+"""Shared-memory transport between agent processes and the server's batching threads.
+
+Stands where the reference has three pickling multiprocessing.Queues (Server.py:73-75 prediction_q /
+training_q, ProcessAgent.py:64 wait_q).  A thin numpy/ctypes face over libga3c_host.so
+(include/ga3c_host.h): agents write a state straight into their slot of one POSIX shm segment and
+sleep on a futex; predictors pop ids from a lock-free ring, read the slots, answer in place.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+import _native as nat
+
+TIMEOUT, CLOSED = -3, -4
+
+
+class Transport:
+    def __init__(self, handle, owner):
+        self._lib = nat.host_lib()
+        self._h = handle
+        self.owner = owner
+        cfg = nat.ShmConfig()
+        nat.check_host(self._lib.ga3c_shm_get_config(self._h, C.byref(cfg)))
+        self.max_agents, self.num_actions = cfg.max_agents, cfg.num_actions
+        self.state_bytes, self.train_slots, self.train_rows = cfg.state_bytes, cfg.train_slots, cfg.train_rows
+        self.nbytes = self._lib.ga3c_shm_bytes(self._h)
+        self.base = self._lib.ga3c_shm_base(self._h)
+        self._raw = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.base), dtype=np.uint8)
+        off0 = self._lib.ga3c_shm_state_offset(self._h, 0)
+        stride = self._lib.ga3c_shm_agent_stride(self._h)
+        # [max_agents, state_bytes] strided view over every agent's state
+        self.agent_states = np.lib.stride_tricks.as_strided(self._raw[off0:], shape=(self.max_agents, self.state_bytes),
+                                                            strides=(stride, 1), writeable=True)
+        self._ro_off0 = self._lib.ga3c_shm_rollout_offset(self._h, 0)
+        self._ro_stride = self._lib.ga3c_shm_rollout_stride(self._h)
+
+    # ---- lifecycle
+    @classmethod
+    def create(cls, name, max_agents, num_actions, state_bytes, train_slots, train_rows):
+        cfg = nat.ShmConfig(max_agents, num_actions, state_bytes, train_slots, train_rows)
+        h = C.c_void_p()
+        nat.check_host(nat.host_lib().ga3c_shm_create(name.encode(), C.byref(cfg), C.byref(h)), "ga3c_shm_create")
+        t = cls(h, True)
+        t.name = name
+        return t
+
+    @classmethod
+    def attach(cls, name):
+        h = C.c_void_p()
+        nat.check_host(nat.host_lib().ga3c_shm_attach(name.encode(), C.byref(h)), "ga3c_shm_attach")
+        t = cls(h, False)
+        t.name = name
+        return t
+
+    def shutdown(self):
+        self._lib.ga3c_shm_shutdown(self._h)
+
+    def close(self):
+        if self._h:
+            self._raw = self.agent_states = None
+            self._lib.ga3c_shm_close(self._h, 1 if self.owner else 0)
+            self._h = None
+
+    # ---- agent side of predict
+    def state_view(self, agent, dtype=np.uint8):
+        return self.agent_states[agent].view(dtype)
+
+    def submit(self, agent):
+        return nat.check_host(self._lib.ga3c_pq_submit(self._h, agent), "ga3c_pq_submit")
+
+    def wait(self, agent, timeout_ms=-1):
+        p = np.empty(self.num_actions, np.float32)
+        v = C.c_float()
+        rc = nat.check_host(self._lib.ga3c_pq_wait(self._h, agent, nat.ptr(p), C.byref(v), timeout_ms), "ga3c_pq_wait")
+        return rc, p, v.value
+
+    # ---- predictor side
+    def pop_batch(self, ids, timeout_ms):
+        return nat.check_host(self._lib.ga3c_pq_pop_batch(self._h, nat.ptr(ids, nat.u32p), ids.size, timeout_ms),
+                              "ga3c_pq_pop_batch")
+
+    def respond(self, ids, n, p, v):
+        nat.check_host(self._lib.ga3c_pq_respond(self._h, nat.ptr(ids, nat.u32p), n, nat.ptr(p), nat.ptr(v)),
+                       "ga3c_pq_respond")
+
+    # ---- training queue
+    def rollout_views(self, slot):
+        base = self._ro_off0 + slot * self._ro_stride
+        states = self._raw[base: base + self.train_rows * self.state_bytes].reshape(self.train_rows, self.state_bytes)
+        rp = self._lib.ga3c_tq_returns(self._h, slot)
+        ap = self._lib.ga3c_tq_actions(self._h, slot)
+        returns = np.frombuffer((C.c_float * self.train_rows).from_address(rp), dtype=np.float32)
+        actions = np.frombuffer((C.c_int32 * self.train_rows).from_address(ap), dtype=np.int32)
+        return states, returns, actions
+
+    def acquire(self, timeout_ms):
+        return nat.check_host(self._lib.ga3c_tq_acquire(self._h, timeout_ms), "ga3c_tq_acquire")
+
+    def commit(self, slot, rows):
+        nat.check_host(self._lib.ga3c_tq_commit(self._h, slot, rows), "ga3c_tq_commit")
+
+    def pop_rollout(self, timeout_ms):
+        return nat.check_host(self._lib.ga3c_tq_pop(self._h, timeout_ms), "ga3c_tq_pop")
+
+    def rows(self, slot):
+        return nat.check_host(self._lib.ga3c_tq_rows(self._h, slot), "ga3c_tq_rows")
+
+    def release(self, slot):
+        nat.check_host(self._lib.ga3c_tq_release(self._h, slot), "ga3c_tq_release")
+
+    def ready_count(self):
+        return self._lib.ga3c_tq_ready_count(self._h)
+
+
+def unique_name(tag="ga3c"):
+    return "/%s_%d_%d" % (tag, os.getpid(), int.from_bytes(os.urandom(3), "little"))
+
+
+def accumulate_rewards_fork(rewards, gamma, terminal_reward, discounting=True, use_intermediate_reward=False):
+    """ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84) through the C ABI, f64, bit-exact."""
+    r = np.ascontiguousarray(rewards, dtype=np.float64)
+    out = np.empty_like(r)
+    nat.check_host(nat.host_lib().ga3c_returns_fork(nat.ptr(r, nat.f64p), r.size, float(gamma), float(terminal_reward),
+                                                    int(bool(discounting)), int(bool(use_intermediate_reward)),
+                                                    nat.ptr(out, nat.f64p)), "ga3c_returns_fork")
+    return out
+
+
+def returns_nstep(rewards, gamma, bootstrap_value, rmin=-1.0, rmax=1.0):
+    r = np.ascontiguousarray(rewards, dtype=np.float64)
+    out = np.empty(max(r.size - 1, 0), np.float64)
+    if r.size > 1:
+        nat.check_host(nat.host_lib().ga3c_returns_nstep(nat.ptr(r, nat.f64p), r.size, float(gamma), float(bootstrap_value),
+                                                         float(rmin), float(rmax), nat.ptr(out, nat.f64p)),
+                       "ga3c_returns_nstep")
+    return out

@@ -48,6 +48,7 @@ HIP_SIGNATURES = {
     "ga3c_net_predict": (C.c_int, [C.c_void_p, f32p, C.c_int32, f32p, f32p, f32p]),
     "ga3c_net_predict_u8": (C.c_int, [C.c_void_p, u8p, C.c_int32, f32p, f32p, f32p]),
     "ga3c_net_train": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
+    "ga3c_net_train_u8": (C.c_int, [C.c_void_p, u8p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_compute_grads": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32, C.c_float, f32p]),
     "ga3c_net_apply_grads": (C.c_int, [C.c_void_p, C.c_float]),
     "ga3c_net_upload": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32]),

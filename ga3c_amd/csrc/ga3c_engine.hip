@@ -288,16 +288,23 @@ int train_apply(ga3c_net* net, float lr) {
   return GA3C_OK;
 }
 
-int stage_train_inputs(ga3c_net* net, const float* x, const float* y_r, const float* a, int B) {
+int stage_train_inputs(ga3c_net* net, const void* x, bool u8, const float* y_r, const float* a, int B) {
   TrainLane& t = net->tr;
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
-  const size_t xb = (size_t)B * XS * sizeof(float);
   if (x) {
+    const size_t xb = (size_t)B * XS * (u8 ? 1 : sizeof(float));
+    void* dst = u8 ? (void*)t.f.xu8 : (void*)t.f.x;
     if (is_pinned(x)) {
-      HIPCHK(hipMemcpyAsync(t.f.x, x, xb, hipMemcpyHostToDevice, t.st));
+      HIPCHK(hipMemcpyAsync(dst, x, xb, hipMemcpyHostToDevice, t.st));
     } else {
       memcpy(t.h_in, x, xb);
-      HIPCHK(hipMemcpyAsync(t.f.x, t.h_in, xb, hipMemcpyHostToDevice, t.st));
+      HIPCHK(hipMemcpyAsync(dst, t.h_in, xb, hipMemcpyHostToDevice, t.st));
+    }
+    if (u8) {
+      const int64_t n4 = (int64_t)xb / 4;
+      int blocks = (int)((n4 + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(u8_to_f32_kernel, dim3(blocks), dim3(256), 0, t.st, t.f.xu8, t.f.x, n4);
     }
   }
   float* hy = t.h_in + (size_t)net->maxB * XS;
@@ -595,7 +602,7 @@ int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, cons
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, y_r, a, batch));
+  CHK(stage_train_inputs(net, x, false, y_r, a, batch));
   CHK(train_grads(net, batch, beta));
   return read_losses(net, losses);
 }
@@ -614,7 +621,18 @@ int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float*
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, y_r, a, batch));
+  CHK(stage_train_inputs(net, x, false, y_r, a, batch));
+  CHK(train_grads(net, batch, beta));
+  CHK(train_apply(net, learning_rate));
+  return read_losses(net, losses);
+}
+
+int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch,
+                      float learning_rate, float beta, float* losses) {
+  if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(stage_train_inputs(net, x, true, y_r, a, batch));
   CHK(train_grads(net, batch, beta));
   CHK(train_apply(net, learning_rate));
   return read_losses(net, losses);
@@ -624,7 +642,7 @@ int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float
   if (!net || !x) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, y_r, a, batch));
+  CHK(stage_train_inputs(net, x, false, y_r, a, batch));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
 }

@@ -84,6 +84,9 @@ int ga3c_net_predict_u8(ga3c_net* net, const uint8_t* x, int32_t batch, float* p
  * {cost_p_1_agg, cost_p_2_agg, cost_v} (NetworkVP_discrate.py:61,83-84) of this rank's rows. */
 int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch,
                    float learning_rate, float beta, float* losses);
+/* Same, states as uint8 frames (converted on the GPU exactly like ga3c_net_predict_u8). */
+int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch,
+                      float learning_rate, float beta, float* losses);
 /* The two halves of train, for tests and for callers that own the exchange step:
  * gradients only (left in arena 3), then the optimizer step on arena 3. */
 int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, const float* a,

