@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--actions", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length; 0 disables it")
+    ap.add_argument("--e2e-seconds", type=float, default=8.0,
+                    help="also run the whole engine (agent processes -> transport -> predictor/trainer threads) this long; 0 disables")
+    ap.add_argument("--e2e-agents", type=int, default=32)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,6 +160,7 @@ def main():
     # ---- CPU baseline: the oracle's C port on this box's host cores (rank 0, N = 1 only)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         import ga3c_oracle_cport as oc
+        oc.lib().ga3c_oc_set_threads(min(os.cpu_count() or 1, 16))   # a one-GPU box's CPU share is 16 cores
         theta = net.get_arena(0)
         oc.predict(theta, A, x)
         n, t0 = 0, time.perf_counter()
@@ -178,6 +182,32 @@ def main():
                                "train_steps_per_sec": m / dt2}
 
     net.close()
+
+    # ---- whole engine, BASELINE configs[1]/[2] shape: agents -> shm transport -> ThreadPredictor / ThreadTrainer -> HIP
+    if rank == 0 and world == 1 and args.e2e_seconds > 0:
+        from Server import Server
+        Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = args.e2e_agents, 2, 2
+        Config.TRAINING_MIN_BATCH_SIZE = B - 1
+        Config.DYNAMIC_SETTINGS, Config.SAVE_MODELS, Config.TENSORBOARD = False, False, False
+        Config.PRINT_STATS_FREQUENCY = 10 ** 9
+        Config.RESULTS_FILENAME = os.devnull
+        Config.NUM_ACTIONS = A
+        real_stdout = sys.stdout
+        sys.stdout = sys.stderr
+        try:
+            srv = Server(max_agents=args.e2e_agents)
+            t0 = time.perf_counter()
+            srv.main(max_seconds=args.e2e_seconds)
+            dt = time.perf_counter() - t0
+            out["e2e"] = {"predictions_per_sec": srv.predictions_served / dt, "training_steps_per_sec": srv.training_step / dt,
+                          "seconds": dt, "agents": args.e2e_agents, "predictors": 2, "trainers": 2,
+                          "train_rows_per_step": srv.frame_counter / max(srv.training_step, 1),
+                          "note": "synthetic Python agents (PCG64 frames) on this box's host cores; counts predictions "
+                                  "served and train steps taken by the engine, start-up included"}
+            srv.model.close()
+        finally:
+            sys.stdout = real_stdout
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

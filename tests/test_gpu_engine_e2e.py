@@ -31,8 +31,9 @@ def test_engine_trains_on_gpu(tmp_path, monkeypatch):
         # checkpoint round trip through the reference's naming scheme (checkpoints/<name>_%08d)
         srv.model.save(7)
         srv.model.set_arena(0, np.zeros_like(after))
-        Config.LOAD_EPISODE = 0
+        Config.LOAD_EPISODE = 7          # the run itself may have saved later episodes (SAVE_FREQUENCY)
         assert srv.model.load() == 7
+        Config.LOAD_EPISODE = 0
         assert np.array_equal(srv.model.get_arena(0), after)
         p, v = srv.model.predict_p_and_v(np.zeros((3, 84, 84, 4), np.float32))
         assert np.allclose(p.sum(axis=1), 1.0, atol=1e-5)
