@@ -74,10 +74,8 @@ def main():
     net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=1)
     lib, h = net._lib, net._h
 
-    if world > 1:
-        cid = torch.from_numpy(Network.make_comm_id() if rank == 0 else np.zeros(nat.COMM_ID_BYTES, np.uint8))
-        dist.broadcast(cid, src=0)
-        net.comm_init(cid.numpy(), rank, world)
+    import DataParallel
+    DataParallel.attach(net, rank, world)      # RCCL communicator; the 128-byte id travels over the gloo group
 
     # synthetic inputs of the reference's shape and value set
     rng = np.random.Generator(np.random.PCG64(12345 + rank))

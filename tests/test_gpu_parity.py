@@ -172,3 +172,24 @@ def test_bad_shapes_are_rejected(nets):
         net.predict_p_and_v(np.zeros((161, 84, 84, 4), np.float32))
     with pytest.raises(RuntimeError):
         net.predict_p_and_v(np.zeros((0, 84, 84, 4), np.float32))
+
+
+def test_rccl_single_rank_communicator_allreduce_is_identity():
+    """The multi-GPU exchange step cannot be exercised on a one-GPU box; this checks that the RCCL path
+    links, initialises and runs (a 1-rank sum all-reduce leaves the gradient arena unchanged)."""
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    net = Network("gpu:0", "dp", 6, (84, 84, 4), max_batch=16, predict_lanes=1)
+    try:
+        _, x, a, y = _batch(8, 6, 3)
+        net.compute_grads(x, y, a)
+        before = net.get_arena(3)
+        net.comm_init(Network.make_comm_id(), 0, 1)
+        import _native as nat
+        nat.check(net._lib.ga3c_net_allreduce_grads(net._h), "allreduce")
+        assert np.array_equal(net.get_arena(3), before)
+        net.learning_rate = 3e-4
+        net.train(x, y, a)                      # the train path with a communicator attached
+        assert np.all(np.isfinite(net.get_arena(0)))
+    finally:
+        net.close()
