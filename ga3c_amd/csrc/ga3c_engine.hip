@@ -104,6 +104,7 @@ struct ga3c_net {
   int maxB = 0;
   int64_t n = 0;   // arena floats
   float* theta[2] = {nullptr, nullptr};
+  float* theta_pk[2] = {nullptr, nullptr};   // dense1/w of theta[i] in dense1_fwd's fragment order
   int cur = 0;
   float *grad = nullptr, *ms = nullptr, *mom = nullptr;
   hipEvent_t theta_ready[2] = {nullptr, nullptr};
@@ -159,25 +160,16 @@ bool is_pinned(const void* p) {
 }
 
 // ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
-int launch_forward(ga3c_net* net, const Fwd& f, const float* th, int B, hipStream_t st, bool train,
+int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, bool train,
                    const TrainLane* tl, float beta) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
-  {
-    const int M = B * P1, nt = (M + 15) / 16;
-    int blocks = (nt + 3) / 4;
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, M, nt);
-  }
-  {
-    const int M = B * P2, nt = (M + 15) / 16;
-    int blocks = (nt + 3) / 4;
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(blocks), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, M, nt);
-  }
+  const float* th = net->theta[idx];
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * 7), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, B);
+  hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
   const int ks = dense_ks(B);
-  hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 15) / 16, ks), dim3(256), 0, st, f.n2, th + OFF_WD, f.part, B,
-                     KSTEPS_DENSE / ks);
+  hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 31) / 32, ks, 2), dim3(256), 0, st, f.n2, net->theta_pk[idx], f.part,
+                     B, KSTEPS_DENSE / ks);
   HeadArgs h;
   memset(&h, 0, sizeof h);
   h.part = f.part; h.ks = ks; h.B = B; h.A = A;
@@ -257,20 +249,20 @@ int lane_forward(ga3c_net* net, Lane& L, int B) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->cur;
   HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
-  CHK(launch_forward(net, L.f, net->theta[idx], B, L.st, false, nullptr, 0.f));
+  CHK(launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   return GA3C_OK;
 }
 
 // gradients of the batch staged in the train lane -> net->grad (train lane mutex held by caller)
 int train_grads(ga3c_net* net, int B, float beta) {
-  const float* th;
+  int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    th = net->theta[net->cur];   // only this lane's stream ever flips it, and that is ordered behind us
+    idx = net->cur;   // only this lane's stream ever flips it, and that is ordered behind us
   }
-  CHK(launch_forward(net, net->tr.f, th, B, net->tr.st, true, &net->tr, beta));
-  CHK(launch_backward(net, th, B));
+  CHK(launch_forward(net, net->tr.f, idx, B, net->tr.st, true, &net->tr, beta));
+  CHK(launch_backward(net, net->theta[idx], B));
   return GA3C_OK;
 }
 
@@ -282,6 +274,9 @@ int train_apply(ga3c_net* net, float lr) {
   const int idx = net->cur, other = 1 - idx;
   for (Lane* L : net->lanes) HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
   CHK(launch_rmsprop(net, net->theta[idx], net->theta[other], lr, t.st));
+  hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, t.st, net->theta[other] + OFF_WD,
+                     net->theta_pk[other]);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
   net->cur = other;
   net->step += 1;
@@ -445,6 +440,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   } while (0)
   for (int i = 0; i < 2; ++i) {
     TRY(dmalloc(&net->theta[i], (size_t)net->n));
+    TRY(dmalloc(&net->theta_pk[i], (size_t)FLAT * HID));
     TRYHIP(hipEventCreateWithFlags(&net->theta_ready[i], hipEventDisableTiming));
   }
   TRY(dmalloc(&net->grad, (size_t)net->n));
@@ -525,6 +521,7 @@ int ga3c_net_destroy(ga3c_net* net) {
   if (t.st) (void)hipStreamDestroy(t.st);
   for (int i = 0; i < 2; ++i) {
     if (net->theta[i]) (void)hipFree(net->theta[i]);
+    if (net->theta_pk[i]) (void)hipFree(net->theta_pk[i]);
     if (net->theta_ready[i]) (void)hipEventDestroy(net->theta_ready[i]);
   }
   for (float* p : {net->grad, net->ms, net->mom})
@@ -572,6 +569,12 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
   float* dst = arena_ptr(net, which);
   if (!dst) return fail(GA3C_EINVAL, "arena selector %d not in [0,3]", which);
   HIPCHK(hipMemcpy(dst, in, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+  if (which == 0) {
+    hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, net->tr.st, net->theta[net->cur] + OFF_WD,
+                       net->theta_pk[net->cur]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(net->tr.st));
+  }
   return GA3C_OK;
 }
 
@@ -648,12 +651,12 @@ int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float
 }
 
 static int resident_predict_locked(ga3c_net* net, int B) {
-  const float* th;
+  int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    th = net->theta[net->cur];
+    idx = net->cur;
   }
-  return launch_forward(net, net->tr.f, th, B, net->tr.st, false, nullptr, 0.f);
+  return launch_forward(net, net->tr.f, idx, B, net->tr.st, false, nullptr, 0.f);
 }
 
 int ga3c_net_predict_resident(ga3c_net* net, int32_t batch) {
@@ -717,18 +720,12 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
 #define TL(kern, grid, ...) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, t.st, t.ev0, t.ev1, 0, __VA_ARGS__)
   for (int i = 0; i < iters; ++i) {
     if (k == "conv1_fwd") {
-      const int M = B * P1, nt = (M + 15) / 16;
-      int blocks = (nt + 3) / 4;
-      if (blocks > 512) blocks = 512;
-      TL(conv1_fwd_kernel, dim3(blocks), t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, M, nt);
+      TL(conv1_fwd_kernel, dim3(B * 7), t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, B);
     } else if (k == "conv2_fwd") {
-      const int M = B * P2, nt = (M + 15) / 16;
-      int blocks = (nt + 3) / 4;
-      if (blocks > 512) blocks = 512;
-      TL(conv2_fwd_kernel, dim3(blocks), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, M, nt);
+      TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
-      TL(dense1_fwd_kernel, dim3((B + 15) / 16, ks), t.f.n2, th + OFF_WD, t.f.part, B, KSTEPS_DENSE / ks);
+      TL(dense1_fwd_kernel, dim3((B + 31) / 32, ks, 2), t.f.n2, net->theta_pk[net->cur], t.f.part, B, KSTEPS_DENSE / ks);
     } else if (k == "conv1_dw") {
       const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
       TL(conv1_dw_kernel, dim3(nch), t.f.x, t.dn1, t.slab1, P, ch);

