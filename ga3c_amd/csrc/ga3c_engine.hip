@@ -71,6 +71,7 @@ struct Lane {
   float* h_in = nullptr;    // pinned staging, max_batch states
   float* h_out = nullptr;   // pinned staging, p|v|z
   hipEvent_t read_done[2] = {nullptr, nullptr};
+  bool dirty[2] = {false, false};   // read_done[i] recorded since theta[i] was last written (guarded by wmu)
 };
 
 struct TrainLane {
@@ -108,6 +109,8 @@ struct ga3c_net {
   int cur = 0;
   float *grad = nullptr, *ms = nullptr, *mom = nullptr;
   hipEvent_t theta_ready[2] = {nullptr, nullptr};
+  bool ready_recorded[2] = {false, false};
+  std::mutex ready_mu;
   std::shared_mutex wmu;   // shared: a forward pass picking/reading theta[cur]; unique: the optimizer flip
   std::vector<Lane*> lanes;
   std::atomic<unsigned> rr{0};
@@ -222,19 +225,18 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   return GA3C_OK;
 }
 
-int launch_rmsprop(ga3c_net* net, const float* tin, float* tout, float lr, hipStream_t st) {
+int launch_rmsprop(ga3c_net* net, const float* tin, float* tout, float* pk_out, float lr, hipStream_t st) {
   const bool clip = net->cfg.flags & GA3C_FLAG_GRAD_CLIP;
   const bool mom = net->cfg.rmsprop_momentum != 0.0f;
   const float omr = 1.0f - net->cfg.rmsprop_decay;
-  int blocks = (int)((net->n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
   if (clip)
     hipLaunchKernelGGL(clip_scale_kernel, dim3(10), dim3(256), 0, st, net->grad, net->tt, net->cfg.grad_clip_norm,
                        net->tr.scales);
 #define RMS(C, M)                                                                                                \
   hipLaunchKernelGGL((rmsprop_kernel<C, M>), dim3(blocks), dim3(256), 0, st, tin, tout, net->ms, net->mom,        \
                      net->grad, net->n, lr, omr, net->cfg.rmsprop_momentum, net->cfg.rmsprop_epsilon, net->tt,    \
-                     net->tr.scales)
+                     net->tr.scales, pk_out)
   if (clip && mom) RMS(true, true);
   else if (clip) RMS(true, false);
   else if (mom) RMS(false, true);
@@ -248,9 +250,18 @@ int launch_rmsprop(ga3c_net* net, const float* tin, float* tout, float lr, hipSt
 int lane_forward(ga3c_net* net, Lane& L, int B) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->cur;
+  {
+    std::lock_guard<std::mutex> g(net->ready_mu);
+    if (!net->ready_recorded[idx]) {
+      // first reader since the optimizer wrote theta[idx]: mark the tail of the train stream
+      HIPCHK(hipEventRecord(net->theta_ready[idx], net->tr.st));
+      net->ready_recorded[idx] = true;
+    }
+  }
   HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
   CHK(launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
+  L.dirty[idx] = true;
   return GA3C_OK;
 }
 
@@ -272,12 +283,16 @@ int train_apply(ga3c_net* net, float lr) {
     NCCLCHK(ncclAllReduce(net->grad, net->grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
   std::unique_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->cur, other = 1 - idx;
-  for (Lane* L : net->lanes) HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
-  CHK(launch_rmsprop(net, net->theta[idx], net->theta[other], lr, t.st));
-  hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, t.st, net->theta[other] + OFF_WD,
-                     net->theta_pk[other]);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
+  // Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only
+  // when a prediction lane has really touched the buffer about to be overwritten.
+  for (Lane* L : net->lanes) {
+    if (L->dirty[other]) {
+      HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
+      L->dirty[other] = false;
+    }
+  }
+  CHK(launch_rmsprop(net, net->theta[idx], net->theta[other], net->theta_pk[other], lr, t.st));
+  net->ready_recorded[other] = false;   // a lane that needs this buffer records theta_ready itself (lane_forward)
   net->cur = other;
   net->step += 1;
   return GA3C_OK;
@@ -742,10 +757,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "dense1_dx") {
       TL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), t.dd1, th + OFF_WD, t.f.n2, t.dn2, B);
     } else if (k == "rmsprop") {
-      int blocks = (int)((net->n + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
+      const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
       TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->cur], net->ms, net->mom, net->grad, net->n,
-         0.0f, 1.0f - net->cfg.rmsprop_decay, 0.0f, net->cfg.rmsprop_epsilon, net->tt, t.scales);
+         0.0f, 1.0f - net->cfg.rmsprop_decay, 0.0f, net->cfg.rmsprop_epsilon, net->tt, t.scales,
+         net->theta_pk[net->cur]);
     } else {
       return fail(GA3C_EINVAL, "unknown kernel '%s'", kernel);
     }

@@ -766,30 +766,63 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ RMSProp (TF-1.x ApplyRMSProp arithmetic)
 // ms += (g*g - ms)*(1-rho); mom = mom*mu + (g*lr)/sqrt(eps+ms); theta_out = theta_in - mom.
-// theta_in/theta_out are the two halves of the double-buffered weights.
+// theta_in/theta_out are the two halves of the double-buffered weights.  Blocks [0,242) own one 16-row
+// group of dense1/w each (thread n: rows 16s..16s+15 of column n), which is exactly one 64-byte row of the
+// fragment-ordered copy pk_out that dense1_fwd reads; the remaining blocks sweep the rest of the arena.
+template <bool CLIP, bool MOM>
+__device__ __forceinline__ float rmsprop_one(int64_t i, const float* __restrict__ theta_in, float* __restrict__ theta_out,
+                                             float* __restrict__ ms, float* __restrict__ mom,
+                                             const float* __restrict__ grad, float lr, float one_minus_rho, float mu,
+                                             float eps, float scale) {
+  float g = grad[i];
+  if (CLIP) g *= scale;
+  float m = ms[i];
+  m += (g * g - m) * one_minus_rho;
+  ms[i] = m;
+  float step = (g * lr) / sqrtf(eps + m);
+  if (MOM) {
+    step = mom[i] * mu + step;
+    mom[i] = step;
+  }
+  const float tn = theta_in[i] - step;
+  theta_out[i] = tn;
+  return tn;
+}
+
+constexpr int RMS_WD_BLOCKS = KSTEPS_DENSE;   // 242
 template <bool CLIP, bool MOM>
 __global__ __launch_bounds__(256) void rmsprop_kernel(const float* __restrict__ theta_in, float* __restrict__ theta_out,
                                                       float* __restrict__ ms, float* __restrict__ mom,
                                                       const float* __restrict__ grad, int64_t n, float lr,
                                                       float one_minus_rho, float mu, float eps, TensorTable tt,
-                                                      const float* __restrict__ scales) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float g = grad[i];
+                                                      const float* __restrict__ scales, float* __restrict__ pk_out) {
+  if (blockIdx.x < RMS_WD_BLOCKS) {
+    const int s = blockIdx.x, col = threadIdx.x;
+    const float sc = CLIP ? scales[4] : 1.0f;            // tensor 4 = dense1/w
+    float v[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      v[kk] = rmsprop_one<CLIP, MOM>(OFF_WD + (int64_t)(s * 16 + kk) * HID + col, theta_in, theta_out, ms, mom, grad, lr,
+                                     one_minus_rho, mu, eps, sc);
+    float* dst = pk_out + ((size_t)s * HID + col) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(dst + 4 * q) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    return;
+  }
+  // everything except dense1/w: [0, OFF_WD) and [OFF_BD, n)
+  const int64_t rest = OFF_WD + (n - OFF_BD);
+  for (int64_t j = (int64_t)(blockIdx.x - RMS_WD_BLOCKS) * 256 + threadIdx.x; j < rest;
+       j += (int64_t)(gridDim.x - RMS_WD_BLOCKS) * 256) {
+    const int64_t i = j < OFF_WD ? j : j - OFF_WD + OFF_BD;
+    float sc = 1.0f;
     if (CLIP) {
       int ti = 0;
 #pragma unroll
       for (int k = 1; k < 10; ++k) ti += (i >= tt.off[k]) ? 1 : 0;
-      g *= scales[ti];
+      sc = scales[ti];
     }
-    float m = ms[i];
-    m += (g * g - m) * one_minus_rho;
-    ms[i] = m;
-    float step = (g * lr) / sqrtf(eps + m);
-    if (MOM) {
-      step = mom[i] * mu + step;
-      mom[i] = step;
-    }
-    theta_out[i] = theta_in[i] - step;
+    rmsprop_one<CLIP, MOM>(i, theta_in, theta_out, ms, mom, grad, lr, one_minus_rho, mu, eps, sc);
   }
 }
 
