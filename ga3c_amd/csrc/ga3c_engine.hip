@@ -180,7 +180,7 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   h.d1 = f.d1; h.z = f.z; h.p = f.p; h.v = f.v;
   h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
   h.log_softmax = (net->cfg.flags & GA3C_FLAG_LOG_SOFTMAX) ? 1 : 0;
-  if (train) { h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.beta = beta; }
+  if (train) { h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.dd1 = tl->dd1; h.beta = beta; }
 #define HEADS(T, AM) hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + 3) / 4), dim3(256), 0, st, h)
   if (A <= 8) { if (train) HEADS(true, 8); else HEADS(false, 8); }
   else if (A <= 24) { if (train) HEADS(true, 24); else HEADS(false, 24); }
@@ -196,30 +196,26 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   hipStream_t st = t.st;
   float* g = net->grad;
   HeadBwdArgs hb;
-  hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.wp = th + OFF_WP; hb.wv = th + OFF_WV;
-  hb.lossrow = t.lossrow; hb.dd1 = t.dd1; hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV;
-  hb.g_bv = g + OFF_BV; hb.losses = t.losses;
-  hipLaunchKernelGGL(heads_bwd_kernel, dim3(B + A + 2), dim3(256), 0, st, hb);
-  hipLaunchKernelGGL(dense1_dw_kernel, dim3(FLAT / 32, 2), dim3(256), 0, st, t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD, B);
+  hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
+  hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV; hb.g_bv = g + OFF_BV; hb.losses = t.losses;
+  hipLaunchKernelGGL(dense1_dw_kernel, dim3(FLAT / 32 + A + 2, 2), dim3(256), 0, st, t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD,
+                     B, hb);
   hipLaunchKernelGGL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), dim3(256), 0, st, t.dd1,
                      th + OFF_WD, t.f.n2, t.dn2, B);
-  {
-    const int P = B * P2, ch = chunk2(B), nch = (P + ch - 1) / ch;
-    hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch, 2), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, P, ch);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB2 + 63) / 64), dim3(1024), 0, st, t.slab2, nch, SLAB2, 256 * 32,
-                       g + OFF_W2, g + OFF_B2);
-  }
+  const int P2n = B * P2, ch2 = chunk2(B), nch2 = (P2n + ch2 - 1) / ch2;
+  hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 2), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, P2n, ch2);
   {
     const int nt = (B * P2 + 15) / 16;
     int blocks = (nt + 3) / 4;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(conv2_dx_kernel, dim3(blocks, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
   }
+  const int P1n = B * P1, ch1 = chunk1(B), nch1 = (P1n + ch1 - 1) / ch1;
+  hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch1), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, P1n, ch1);
   {
-    const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
-    hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, P, ch);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((SLAB1 + 63) / 64), dim3(1024), 0, st, t.slab1, nch, SLAB1, 256 * 16,
-                       g + OFF_W1, g + OFF_B1);
+    SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
+    SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2);
   }
   HIPCHK(hipGetLastError());
   return GA3C_OK;
@@ -753,7 +749,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       if (blocks > 256) blocks = 256;
       TL(conv2_dx_kernel, dim3(blocks, 4), t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
     } else if (k == "dense1_dw") {
-      TL(dense1_dw_kernel, dim3(FLAT / 32, 2), t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD, B);
+      HeadBwdArgs hb;
+      hb.B = B; hb.A = net->A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
+      hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(net->A); hb.g_wv = g + OFF_WV; hb.g_bv = g + OFF_BV; hb.losses = t.losses;
+      TL(dense1_dw_kernel, dim3(FLAT / 32 + net->A + 2, 2), t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD, B, hb);
     } else if (k == "dense1_dx") {
       TL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), t.dd1, th + OFF_WD, t.f.n2, t.dn2, B);
     } else if (k == "rmsprop") {

@@ -290,13 +290,14 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ heads (+ loss)
 // One wave per sample: d1 = relu(sum_ks part + bd); z = d1 Wp + bp; v = d1 Wv + bv; softmax;
-// TRAIN adds the A3C loss terms and the head gradients dz, dv.
+// TRAIN adds the A3C loss terms, the head gradients dz, dv and the gradient that
+// flows back into the hidden layer, dd1 = 1[d1>0] (dz Wp^T + dv Wv^T) -- the wave already holds Wp, Wv, d1.
 struct HeadArgs {
   const float* part; int ks; int B; int A;
   const float* bd; const float* wv; const float* bv; const float* wp; const float* bp;
   float* d1; float* z; float* p; float* v;
   // train only
-  const float* y_r; const float* act; float* dz; float* dv; float* lossrow;
+  const float* y_r; const float* act; float* dz; float* dv; float* lossrow; float* dd1;
   float beta, log_eps, min_policy; int log_softmax;
 };
 
@@ -378,6 +379,19 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
       dz = s * (gs - dot);
     }
     if (mine) h.dz[(size_t)b * h.A + lane] = dz;
+    {
+      const float dvv = v - y;
+      f32x4 dd = {dvv * wv4[0], dvv * wv4[1], dvv * wv4[2], dvv * wv4[3]};
+#pragma unroll
+      for (int o = 0; o < AMAX; ++o) {
+        const float dzo = __shfl(dz, o, 64);          // 0 for lanes >= A
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dd[q] += dzo * wreg[q][o];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dd[q] = d[q] > 0.f ? dd[q] : 0.f;
+      *reinterpret_cast<f32x4*>(h.dd1 + (size_t)b * HID + 4 * lane) = dd;
+    }
     if (lane == 0) {
       h.dv[b] = v - y;
       h.lossrow[(size_t)b * 3 + 0] = c1;
@@ -387,14 +401,14 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   }
 }
 
-// ------------------------------------------------------------------ heads backward
-// blocks [0,B): dd1[b][k] = 1[d1>0] (sum_o dz[b][o] Wp[k][o] + dv[b] Wv[k])
-// blocks [B,B+A]: o = blk-B; dW[k] = sum_b d1[b][k] dhead[b] (o<A: dWp[:,o]; o==A: dWv), bias by LDS tree
-// block  B+A+1: losses[c] = sum_b lossrow[b][c], fixed order
+// ------------------------------------------------------------------ heads backward (weight gradients)
+// Runs as extra blocks of dense1_dw_kernel (no launch of its own):
+// role o in [0,A]: dW[k] = sum_b d1[b][k] dhead[b] (o<A: dWp[:,o], dbp[o]; o==A: dWv, dbv), LDS fold, fixed order
+// role A+1:        losses[c] = sum_b lossrow[b][c]
 struct HeadBwdArgs {
   int B; int A;
-  const float* d1; const float* dz; const float* dv; const float* wp; const float* wv; const float* lossrow;
-  float* dd1; float* g_wp; float* g_bp; float* g_wv; float* g_bv; float* losses;
+  const float* d1; const float* dz; const float* dv; const float* lossrow;
+  float* g_wp; float* g_bp; float* g_wv; float* g_bv; float* losses;
 };
 
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
@@ -405,18 +419,13 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void heads_bwd_kernel(HeadBwdArgs h) {
+__device__ __forceinline__ void heads_bwd_role(const HeadBwdArgs& h, int role) {
   __shared__ float sh[4];
+  __shared__ f32x4 sacc[4][64];
   const int k = threadIdx.x;
-  const int blk = blockIdx.x;
-  if (blk < h.B) {
-    const int b = blk;
-    float acc = h.dv[b] * h.wv[k];
-    for (int o = 0; o < h.A; ++o) acc += h.dz[(size_t)b * h.A + o] * h.wp[(size_t)k * h.A + o];
-    h.dd1[(size_t)b * HID + k] = h.d1[(size_t)b * HID + k] > 0.f ? acc : 0.f;
-  } else if (blk <= h.B + h.A) {
+  if (role <= h.A) {
     // thread = (4 hidden units kq, batch residue bg): float4 rows of d1, partial sums folded through LDS
-    const int o = blk - h.B;
+    const int o = role;
     const bool isv = o == h.A;
     const int kq = k & 63, bg = k >> 6;
     f32x4 acc = zero4();
@@ -435,7 +444,6 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadBwdArgs h) {
       for (int i = 0; i < 8; ++i) acc += dd[i] * gh[i];
     }
     for (int b = k; b < h.B; b += 256) bsum += isv ? h.dv[b] : h.dz[(size_t)b * h.A + o];
-    __shared__ f32x4 sacc[4][64];
     sacc[bg][kq] = acc;
     bsum = block_sum_256(bsum, sh);   // contains the barriers that also publish sacc
     if (bg == 0) {
@@ -462,9 +470,15 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(HeadBwdArgs h) {
 // ------------------------------------------------------------------ dense1 backward: dWd = flat^T dd1
 // M = 3872 (kidx), N = 256, contraction over the batch.  Wave tile 32 x 32 (2 x 2 MFMA tiles).
 // grid.x = 121 row blocks, grid.y = 2, wave -> 32-column group (grid.y*4 + wave).
-// Row block 0 also produces dbd[n] = sum_b dd1[b][n].
+// Row block 0 also produces dbd[n] = sum_b dd1[b][n].  Blocks with blockIdx.x >= 121 (grid.y == 0 only) carry the
+// head weight gradients and the loss sums (heads_bwd_role).
 __global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dd1,
-                                                        float* __restrict__ g_wd, float* __restrict__ g_bd, int B) {
+                                                        float* __restrict__ g_wd, float* __restrict__ g_bd, int B,
+                                                        HeadBwdArgs hb) {
+  if (blockIdx.x >= FLAT / 32) {   // block-uniform
+    if (blockIdx.y == 0) heads_bwd_role(hb, blockIdx.x - FLAT / 32);
+    return;
+  }
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.x * 32;
   const int n0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 32;
@@ -721,33 +735,37 @@ __global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ slab reduce (fixed order => reproducible)
-// out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e].
-// Block = 16 waves on the same 64 columns; wave w folds chunks w, w+16, ... (8 loads in flight),
-// then wave 0 adds the 16 partial rows in order.
-__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ part, int nchunks, int stride,
-                                                           int nw, float* __restrict__ out_w, float* __restrict__ out_b) {
+// out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e], for two slab sets in one
+// launch (conv1 and conv2 weight-gradient partials).  Block = 16 waves on the same 64 columns; wave w folds
+// chunks w, w+16, ... (8 loads in flight), then wave 0 adds the 16 partial rows in order.
+struct SlabSet { const float* part; int nchunks; int stride; int nw; float* out_w; float* out_b; int nblocks; };
+
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s1) {
   __shared__ float sh[16][64];
+  const bool first = (int)blockIdx.x < s0.nblocks;
+  const SlabSet& ss = first ? s0 : s1;
+  const int blk = first ? blockIdx.x : blockIdx.x - s0.nblocks;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + lane;
-  const bool ok = e < stride;
-  float s0 = 0.f, s1 = 0.f;
-  for (int c0 = w; c0 < nchunks; c0 += 128) {
+  const int e = blk * 64 + lane;
+  const bool ok = e < ss.stride;
+  float a0 = 0.f, a1 = 0.f;
+  for (int c0 = w; c0 < ss.nchunks; c0 += 128) {
     float t[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = c0 + 16 * i;
-      t[i] = (ok && c < nchunks) ? part[(size_t)c * stride + e] : 0.f;
+      t[i] = (ok && c < ss.nchunks) ? ss.part[(size_t)c * ss.stride + e] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 8; i += 2) { s0 += t[i]; s1 += t[i + 1]; }
+    for (int i = 0; i < 8; i += 2) { a0 += t[i]; a1 += t[i + 1]; }
   }
-  sh[w][lane] = s0 + s1;
+  sh[w][lane] = a0 + a1;
   __syncthreads();
   if (w == 0 && ok) {
     float tot = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) tot += sh[i][lane];
-    if (e < nw) out_w[e] = tot; else out_b[e - nw] = tot;
+    if (e < ss.nw) ss.out_w[e] = tot; else ss.out_b[e - ss.nw] = tot;
   }
 }
 
