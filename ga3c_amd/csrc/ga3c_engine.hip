@@ -86,17 +86,6 @@ struct TrainLane {
 };
 
 int dense_ks(int B) { return B <= 256 ? 22 : (B <= 1024 ? 11 : 2); }
-int chunk2(int B) {   // conv2 dW pixel chunk (multiple of 16)
-  const int P = B * P2;
-  int c = ((P + 255) / 256 + 15) / 16 * 16;
-  return c < 128 ? 128 : c;
-}
-int chunk1(int B) {   // conv1 dW pixel chunk (multiple of 16)
-  const int P = B * P1;
-  int c = ((P + 511) / 512 + 15) / 16 * 16;
-  return c < 112 ? 112 : c;
-}
-
 }  // namespace
 
 struct ga3c_net {
@@ -202,16 +191,16 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
                      B, hb);
   hipLaunchKernelGGL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), dim3(256), 0, st, t.dd1,
                      th + OFF_WD, t.f.n2, t.dn2, B);
-  const int P2n = B * P2, ch2 = chunk2(B), nch2 = (P2n + ch2 - 1) / ch2;
-  hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 2), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, P2n, ch2);
+  const int nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
+  hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
   {
     const int nt = (B * P2 + 15) / 16;
     int blocks = (nt + 3) / 4;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(conv2_dx_kernel, dim3(blocks, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
   }
-  const int P1n = B * P1, ch1 = chunk1(B), nch1 = (P1n + ch1 - 1) / ch1;
-  hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch1), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, P1n, ch1);
+  const int nch1 = B * 7 < 512 ? B * 7 : 512;  // workgroups = partial slabs
+  hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch1), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, B * 7);
   {
     SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
     SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
@@ -484,16 +473,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   TRY(dmalloc(&t.dd1, (size_t)maxB * HID));
   TRY(dmalloc(&t.dn2, (size_t)maxB * FLAT));
   TRY(dmalloc(&t.dn1, (size_t)maxB * N1S));
-  {
-    const int P = maxB * P2, ch = chunk2(maxB);
-    size_t nch = (size_t)(P + ch - 1) / ch;
-    if (nch < 256) nch = 256;   // smaller batches use smaller chunks but never more than 256 of them
-    TRY(dmalloc(&t.slab2, nch * SLAB2));
-    const int Pa = maxB * P1, cha = chunk1(maxB);
-    size_t ncha = (size_t)(Pa + cha - 1) / cha;
-    if (ncha < 512) ncha = 512;
-    TRY(dmalloc(&t.slab1, ncha * SLAB1));
-  }
+  TRY(dmalloc(&t.slab2, (size_t)256 * SLAB2));   // conv2_dw: at most 256 sample groups
+  TRY(dmalloc(&t.slab1, (size_t)512 * SLAB1));   // conv1_dw: at most 512 workgroups
   TRY(dmalloc(&t.losses, 4));
   TRY(dmalloc(&t.scales, 16));
   TRYHIP(hipHostMalloc((void**)&t.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
@@ -738,11 +719,9 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       const int ks = dense_ks(B);
       TL(dense1_fwd_kernel, dim3((B + 31) / 32, ks, 2), t.f.n2, net->theta_pk[net->cur], t.f.part, B, KSTEPS_DENSE / ks);
     } else if (k == "conv1_dw") {
-      const int P = B * P1, ch = chunk1(B), nch = (P + ch - 1) / ch;
-      TL(conv1_dw_kernel, dim3(nch), t.f.x, t.dn1, t.slab1, P, ch);
+      TL(conv1_dw_kernel, dim3(B * 7 < 512 ? B * 7 : 512), t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {
-      const int P = B * P2, ch = chunk2(B), nch = (P + ch - 1) / ch;
-      TL(conv2_dw_kernel, dim3(nch, 2), t.f.n1, t.dn2, t.slab2, P, ch);
+      TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
       const int nt = (B * P2 + 15) / 16;
       int blocks = (nt + 3) / 4;

@@ -563,56 +563,75 @@ __global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------ conv2 backward: dW2 partials
 // dW2[kidx][o] = sum_q patch(q)[kidx] dn2[q][o]; kidx = (u*4+v)*16 + c, q over B*121 pixels.
-// m-tile mt = patch position (u,v), lane row = channel c.  Wave = 2 m-tiles x 32 columns.
-// grid.x = pixel chunk, grid.y = 2; wave -> m-group (grid.y*4 + wave), 8 groups of 2 positions.
-// part[chunk][8192 + 32]: the +32 tail is the chunk's db2 (written by m-group 0).
+// m-tile mt = patch position (u,v), lane row = channel c.  Workgroup = (sample group, quarter of the 16 patch
+// positions): a sample's n1 (zero-padded 24x24x16) and dn2 (121 px padded to 128) are staged in LDS, each wave
+// owns one patch position x 32 columns and contracts over the 128 pixel slots (q = 16 s + 4 t + g, so that the
+// four lane groups read neighbouring pixels).  The next sample's loads are in flight during the MFMAs.
+// part[group][8192 + 32]: the +32 tail is the group's db2 (quarter 0, wave 0).  Reduced by slab_reduce_kernel.
 constexpr int SLAB2 = 256 * 32 + 32;
-__global__ __launch_bounds__(256) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
-                                                       float* __restrict__ part, int P, int chunk) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int mg = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int q0 = blockIdx.x * chunk;
-  f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+constexpr int C2DW_IMG = C2_PW * C2_PW * C1;     // 9216 floats
+constexpr int C2DW_DN = 128 * C2;                // 4096 floats
+
+__global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
+                                                          float* __restrict__ part, int B) {
+  __shared__ __attribute__((aligned(16))) float lds[C2DW_IMG + C2DW_DN];
+  float* img = lds;
+  float* dnl = lds + C2DW_IMG;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int mt = blockIdx.y * 4 + wv, u = mt >> 2, v = mt & 3;
+  f32x4 acc0 = zero4(), acc1 = zero4();
   float bs0 = 0.f, bs1 = 0.f;
-  for (int s = 0; s < chunk / 16; ++s) {
-    float a[4][2], bb[4][2];
+  f32x4 simg[9], sdn[4];
+  auto fetch = [&](int b) {
+    const float* nb = n1 + (size_t)b * N1S;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int q = q0 + 16 * s + 4 * g + t;
-      const bool ok = q < P;
-      const int qq = ok ? q : 0;
-      const int b = qq / P2, rem = qq - b * P2, i = rem / O2, j = rem - i * O2;
-      const float* dr = dn2 + (size_t)qq * C2 + r;
-      bb[t][0] = ok ? dr[0] : 0.f;
-      bb[t][1] = ok ? dr[16] : 0.f;
-      const float* nb = n1 + (size_t)b * N1S + r;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int mt = mg * 2 + mi;
-        const int yy = 2 * i - 1 + (mt >> 2), xx = 2 * j - 1 + (mt & 3);
-        const bool in = ok && (unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1;
-        a[t][mi] = in ? nb[(yy * O1 + xx) * C1] : 0.f;
-      }
+    for (int i = 0; i < 9; ++i) {
+      const int idx = threadIdx.x + 256 * i;           // float4 index: pixel = idx>>2, channel quad = idx&3
+      const int px = idx >> 2, row = px / C2_PW, col = px - row * C2_PW;
+      const int yy = row - 1, xx = col - 1;
+      const bool ok = (unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1;
+      simg[i] = ok ? ld4(nb + (yy * O1 + xx) * C1 + (idx & 3) * 4) : zero4();
     }
+    const float* db = dn2 + (size_t)b * FLAT;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bs0 += bb[t][0];
-      bs1 += bb[t][1];
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + 256 * i;           // float4 index into [128 px][32]
+      sdn[i] = idx < FLAT / 4 ? ld4(db + 4 * idx) : zero4();
+    }
+  };
+  int b = blockIdx.x;
+  if (b < B) fetch(b);
+  for (; b < B; b += gridDim.x) {
+    __syncthreads();                                   // everyone is done reading the previous sample
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+    for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(&img[(threadIdx.x + 256 * i) * 4]) = simg[i];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma(a[t][mi], bb[t][ni], acc[mi][ni]);
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&dnl[(threadIdx.x + 256 * i) * 4]) = sdn[i];
+    __syncthreads();
+    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int q = 16 * s + 4 * t + g;
+        const int qc = q < P2 ? q : 0;                 // slots 121..127 carry dn2 = 0
+        const int i = qc / O2, j = qc - i * O2;
+        const float a = img[((2 * i + u) * C2_PW + 2 * j + v) * C1 + r];
+        const float b0 = dnl[q * C2 + r], b1 = dnl[q * C2 + 16 + r];
+        bs0 += b0;
+        bs1 += b1;
+        acc0 = mfma(a, b0, acc0);
+        acc1 = mfma(a, b1, acc1);
+      }
     }
   }
   float* out = part + (size_t)blockIdx.x * SLAB2;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        out[((mg * 2 + mi) * 16 + 4 * g + q) * C2 + ni * 16 + r] = acc[mi][ni][q];
-  if (mg == 0) {
+  for (int q = 0; q < 4; ++q) {
+    out[(mt * 16 + 4 * g + q) * C2 + r] = acc0[q];
+    out[(mt * 16 + 4 * g + q) * C2 + 16 + r] = acc1[q];
+  }
+  if (mt == 0) {
     bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
     bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
     if (g == 0) {
@@ -688,39 +707,67 @@ __global__ __launch_bounds__(256) void conv2_dx_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------ conv1 backward: dW1 partials
 // dW1[kidx][o] = sum_q patch(q)[kidx] dn1[q][o]; kidx = (u*8+v)*4+c; m-tile mt = u*2 + (v>>2),
-// lane row r = (v&3)*4 + c = 16 contiguous floats of one input row.  Wave = 4 m-tiles x 16 columns.
-// grid.x = pixel chunk; wave -> m-group.  part[chunk][4096 + 16] (+16 = db1 of the chunk).
+// lane row r = (v&3)*4 + c = 16 contiguous floats of one input row.  Workgroup walks units = (sample, band of
+// 3 output rows) exactly as conv1_fwd cuts them: the band's 16 padded input rows and its 63 dn1 pixels (padded
+// to 64) are staged in LDS, each wave owns 4 m-tiles x 16 columns and contracts over the 64 pixel slots
+// (q = 16 s + 4 t + g).  The next unit's loads are in flight during the MFMAs.
+// part[workgroup][4096 + 16] (+16 = db1 partial, wave 0).  Reduced by slab_reduce_kernel.
 constexpr int SLAB1 = 256 * 16 + 16;
-__global__ __launch_bounds__(256) void conv1_dw_kernel(const float* __restrict__ x, const float* __restrict__ dn1,
-                                                       float* __restrict__ part, int P, int chunk) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int mg = threadIdx.x >> 6;
-  const int q0 = blockIdx.x * chunk;
+constexpr int C1DW_IMG = C1_RIN * C1_PW * 4;     // 5632 floats
+constexpr int C1DW_DN = 64 * C1;                 // 1024 floats
+
+__global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const float* __restrict__ x, const float* __restrict__ dn1,
+                                                          float* __restrict__ part, int nunits) {
+  __shared__ __attribute__((aligned(16))) float lds[C1DW_IMG + C1DW_DN];
+  float* img = lds;
+  float* dnl = lds + C1DW_IMG;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, mg = threadIdx.x >> 6;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   float bs = 0.f;
-  for (int s = 0; s < chunk / 16; ++s) {
-    float a[4][4], bb[4];
+  f32x4 simg[6], sdn;
+  auto fetch = [&](int unit) {
+    const int b = unit / 7, band = unit - b * 7;
+    const float* xb = x + (size_t)b * XS;
+    const int y_base = 4 * C1_HB * band - 2;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int q = q0 + 16 * s + 4 * g + t;
-      const bool ok = q < P;
-      const int qq = ok ? q : 0;
-      const int b = qq / P1, rem = qq - b * P1, i = rem / O1, j = rem - i * O1;
-      bb[t] = ok ? dn1[(size_t)qq * C1 + r] : 0.f;
-      const float* xb = x + (size_t)b * XS;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int mt = mg * 4 + mi;
-        const int yy = 4 * i - 2 + (mt >> 1), xx = 4 * j - 2 + (mt & 1) * 4 + (r >> 2);
-        const bool in = ok && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-        a[t][mi] = in ? xb[(yy * IMG + xx) * 4 + (r & 3)] : 0.f;
-      }
+    for (int i = 0; i < 6; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int row = idx / C1_PW, col = idx - row * C1_PW;
+      const int yy = y_base + row, xx = col - 2;
+      const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+      simg[i] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
     }
+    const float* db = dn1 + ((size_t)b * P1 + band * C1_HB * O1) * C1;
+    sdn = threadIdx.x < C1_HB * O1 * C1 / 4 ? ld4(db + 4 * threadIdx.x) : zero4();   // 252 float4, slot 63 zero
+  };
+  int unit = blockIdx.x;
+  if (unit < nunits) fetch(unit);
+  for (; unit < nunits; unit += gridDim.x) {
+    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bs += bb[t];
+    for (int i = 0; i < 6; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < C1_RIN * C1_PW) *reinterpret_cast<f32x4*>(&img[idx * 4]) = simg[i];
+    }
+    *reinterpret_cast<f32x4*>(&dnl[threadIdx.x * 4]) = sdn;
+    __syncthreads();
+    if (unit + (int)gridDim.x < nunits) fetch(unit + gridDim.x);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma(a[t][mi], bb[t], acc[mi]);
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int q = 16 * s + 4 * t + g;
+        const int qc = q < C1_HB * O1 ? q : 0;          // slot 63 carries dn1 = 0
+        const int il = qc / O1, j = qc - il * O1;
+        const float bval = dnl[q * C1 + r];
+        bs += bval;
+        const float* ap = img + (4 * il) * (C1_PW * 4) + 16 * j + r;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int mt = mg * 4 + mi;                   // u = mt>>1, vh = mt&1
+          acc[mi] = mfma(ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16], bval, acc[mi]);
+        }
+      }
     }
   }
   float* out = part + (size_t)blockIdx.x * SLAB1;
