@@ -160,8 +160,12 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * 7), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, B);
   hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
   const int ks = dense_ks(B);
-  hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 31) / 32, ks, 2), dim3(256), 0, st, f.n2, net->theta_pk[idx], f.part,
-                     B, KSTEPS_DENSE / ks);
+  if (B <= 256)
+    hipLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
+                       f.part, B, ks, KSTEPS_DENSE / ks);
+  else
+    hipLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
+                       f.part, B, ks, KSTEPS_DENSE / ks);
   HeadArgs h;
   memset(&h, 0, sizeof h);
   h.part = f.part; h.ks = ks; h.B = B; h.A = A;
@@ -717,7 +721,12 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
-      TL(dense1_fwd_kernel, dim3((B + 31) / 32, ks, 2), t.f.n2, net->theta_pk[net->cur], t.f.part, B, KSTEPS_DENSE / ks);
+      if (B <= 256)
+        TL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), t.f.n2, net->theta_pk[net->cur], t.f.part, B, ks,
+           KSTEPS_DENSE / ks);
+      else
+        TL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), t.f.n2, net->theta_pk[net->cur], t.f.part, B, ks,
+           KSTEPS_DENSE / ks);
     } else if (k == "conv1_dw") {
       TL(conv1_dw_kernel, dim3(B * 7 < 512 ? B * 7 : 512), t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {

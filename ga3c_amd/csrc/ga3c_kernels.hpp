@@ -241,43 +241,61 @@ __global__ __launch_bounds__(256) void pack_wd_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------ dense1 forward (split-K)
 // part[ks][b][n] = sum_{k in slice ks} flat[b][k] Wd[k][n];  M = B, N = 256, K = 3872 = 242 steps of 16.
-// Wave tile 32 rows x 32 columns (2 x 2 MFMA tiles), operands as 16-byte loads (flat rows; packed Wd),
-// next step's operands in flight during the current step's 16 MFMAs.
-// grid = (row pairs, KS slices, 2); wave -> 32-column group blockIdx.z*4 + wave.
+// Wave tile (16*MT rows) x 32 columns, operands as 16-byte loads (flat rows; packed Wd), next step's
+// operands in flight during the current step's MFMAs.  1-D grid, XCD-aware: blocks are dealt round-robin
+// to the 8 XCDs, so block id -> (xcd = id % 8, j = id / 8); all row blocks that read the same slice of Wd
+// (same ks, same column half) get the same xcd and share that XCD's L2 copy of it.
+template <int MT>
 __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict__ flat, const float* __restrict__ pk,
-                                                         float* __restrict__ part, int B, int steps_per_slice) {
+                                                         float* __restrict__ part, int B, int ks_total,
+                                                         int steps_per_slice) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 32, ks = blockIdx.y;
-  const int n0 = (blockIdx.z * 4 + (threadIdx.x >> 6)) * 32;
-  const bool v0 = m0 + r < B, v1 = m0 + 16 + r < B;
-  const float* a0p = flat + (size_t)(v0 ? m0 + r : 0) * FLAT + 4 * g;
-  const float* a1p = flat + (size_t)(v1 ? m0 + 16 + r : 0) * FLAT + 4 * g;
+  const int nrow = (B + 16 * MT - 1) / (16 * MT);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int rb = j % nrow, yz = (j / nrow) * 8 + xcd;      // yz = ks * 2 + column half
+  if (yz >= ks_total * 2) return;
+  const int m0 = rb * 16 * MT, ks = yz >> 1;
+  const int n0 = ((yz & 1) * 4 + (threadIdx.x >> 6)) * 32;
+  bool v[MT];
+  const float* ap[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    v[mi] = m0 + 16 * mi + r < B;
+    ap[mi] = flat + (size_t)(v[mi] ? m0 + 16 * mi + r : 0) * FLAT + 4 * g;
+  }
   const float* w0p = pk + (size_t)(n0 + r) * 16 + 4 * g;
   const float* w1p = w0p + 16 * 16;
-  f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) acc[mi][0] = acc[mi][1] = zero4();
   const int s0 = ks * steps_per_slice, s1 = s0 + steps_per_slice;
-  f32x4 a0 = v0 ? ld4(a0p + 16 * s0) : zero4(), a1 = v1 ? ld4(a1p + 16 * s0) : zero4();
-  f32x4 w0 = ld4(w0p + (size_t)s0 * HID * 16), w1 = ld4(w1p + (size_t)s0 * HID * 16);
+  f32x4 a[MT], w0 = ld4(w0p + (size_t)s0 * HID * 16), w1 = ld4(w1p + (size_t)s0 * HID * 16);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) a[mi] = v[mi] ? ld4(ap[mi] + 16 * s0) : zero4();
   for (int s = s0; s < s1; ++s) {
-    f32x4 na0 = zero4(), na1 = zero4(), nw0 = zero4(), nw1 = zero4();
+    f32x4 na[MT], nw0 = zero4(), nw1 = zero4();
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) na[mi] = zero4();
     if (s + 1 < s1) {
-      na0 = v0 ? ld4(a0p + 16 * (s + 1)) : zero4();
-      na1 = v1 ? ld4(a1p + 16 * (s + 1)) : zero4();
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) na[mi] = v[mi] ? ld4(ap[mi] + 16 * (s + 1)) : zero4();
       nw0 = ld4(w0p + (size_t)(s + 1) * HID * 16);
       nw1 = ld4(w1p + (size_t)(s + 1) * HID * 16);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[0][0] = mfma(a0[t], w0[t], acc[0][0]);
-      acc[0][1] = mfma(a0[t], w1[t], acc[0][1]);
-      acc[1][0] = mfma(a1[t], w0[t], acc[1][0]);
-      acc[1][1] = mfma(a1[t], w1[t], acc[1][1]);
-    }
-    a0 = na0; a1 = na1; w0 = nw0; w1 = nw1;
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        acc[mi][0] = mfma(a[mi][t], w0[t], acc[mi][0]);
+        acc[mi][1] = mfma(a[mi][t], w1[t], acc[mi][1]);
+      }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a[mi] = na[mi];
+    w0 = nw0; w1 = nw1;
   }
   float* out = part + ((size_t)ks * B) * HID + n0 + r;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int mr = m0 + mi * 16 + 4 * g + q;
@@ -286,6 +304,10 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
         out[(size_t)mr * HID + 16] = acc[mi][1][q];
       }
     }
+}
+__host__ inline int dense1_fwd_blocks(int B, int ks_total, int mt) {
+  const int nrow = (B + 16 * mt - 1) / (16 * mt);
+  return 8 * nrow * ((ks_total * 2 + 7) / 8);
 }
 
 // ------------------------------------------------------------------ heads (+ loss)
@@ -317,15 +339,13 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   f32x4 d = ld4(h.bd + 4 * lane);
   const float* pp = h.part + (size_t)b * HID + 4 * lane;
   const size_t kstride = (size_t)h.B * HID;
-  int ks = 0;
-  for (; ks + 11 <= h.ks; ks += 11) {   // dense_ks() picks 22, 11 or 2 slices: keep 11 loads in flight
-    f32x4 t[11];
+  {   // dense_ks() picks 22, 11 or 2 slices: all of them in flight at once, summed in slice order
+    f32x4 t[22];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) t[i] = ld4(pp + (size_t)(ks + i) * kstride);
+    for (int i = 0; i < 22; ++i) t[i] = i < h.ks ? ld4(pp + (size_t)i * kstride) : zero4();
 #pragma unroll
-    for (int i = 0; i < 11; ++i) d += t[i];
+    for (int i = 0; i < 22; ++i) d += t[i];
   }
-  for (; ks < h.ks; ++ks) d += ld4(pp + (size_t)ks * kstride);
 #pragma unroll
   for (int q = 0; q < 4; ++q) d[q] = fmaxf(d[q], 0.f);
   *reinterpret_cast<f32x4*>(h.d1 + (size_t)b * HID + 4 * lane) = d;
@@ -485,12 +505,13 @@ __global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict_
   f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
   float bs0 = 0.f, bs1 = 0.f;
   const int nsteps = (B + 15) >> 4;
-  for (int s = 0; s < nsteps; ++s) {
-    float a[4][2], bb[4][2];
+  constexpr int G = 4;   // 16-row batch steps per operand group (64 dword loads in flight behind 64 MFMAs)
+  float ca[G][4][2], cb[G][4][2];
+  auto fetch = [&](int s, float (&a)[4][2], float (&bb)[4][2]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int b = 16 * s + 4 * g + t;
-      const bool ok = b < B;
+      const bool ok = b < B;                 // also false for steps past the end
       const float* fr = flat + (size_t)(ok ? b : 0) * FLAT + m0 + r;
       const float* dr = dd1 + (size_t)(ok ? b : 0) * HID + n0 + r;
       a[t][0] = ok ? fr[0] : 0.f;
@@ -498,15 +519,34 @@ __global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict_
       bb[t][0] = ok ? dr[0] : 0.f;
       bb[t][1] = ok ? dr[16] : 0.f;
     }
+  };
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      bs0 += bb[t][0];
-      bs1 += bb[t][1];
+  for (int i = 0; i < G; ++i) fetch(i, ca[i], cb[i]);
+  for (int s = 0; s < nsteps; s += G) {
+    float na[G][4][2], nb[G][4][2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+    for (int i = 0; i < G; ++i) fetch(s + G + i, na[i], nb[i]);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma(a[t][mi], bb[t][ni], acc[mi][ni]);
+    for (int i = 0; i < G; ++i) {
+      if (s + i < nsteps) {                  // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bs0 += cb[i][t][0];
+          bs1 += cb[i][t][1];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma(ca[i][t][mi], cb[i][t][ni], acc[mi][ni]);
+        }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ca[i][t][0] = na[i][t][0]; ca[i][t][1] = na[i][t][1];
+        cb[i][t][0] = nb[i][t][0]; cb[i][t][1] = nb[i][t][1];
+      }
   }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -539,15 +579,29 @@ __global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict_
   const float* arow = dd1 + (size_t)(valid ? row : 0) * HID + 4 * g;
   const float* b0 = wd + (size_t)(n0 + r) * HID + 4 * g;
   const float* b1 = wd + (size_t)(n0 + 16 + r) * HID + 4 * g;
-  f32x4 acc0 = zero4(), acc1 = zero4();
-#pragma unroll 4
+  // K = 256 only: all 48 operand loads (and the ReLU mask) are issued before the first MFMA
+  f32x4 a[16], w0[16], w1[16];
+#pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const f32x4 a = valid ? ld4(arow + 16 * s) : zero4();
-    const f32x4 w0 = ld4(b0 + 16 * s), w1 = ld4(b1 + 16 * s);
+    a[s] = valid ? ld4(arow + 16 * s) : zero4();
+    w0[s] = ld4(b0 + 16 * s);
+    w1[s] = ld4(b1 + 16 * s);
+  }
+  float mask0[4], mask1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mr = m0 + 4 * g + q;
+    const size_t o = (size_t)(mr < B ? mr : 0) * FLAT + n0 + r;
+    mask0[q] = n2[o];
+    mask1[q] = n2[o + 16];
+  }
+  f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      acc0 = mfma(a[t], w0[t], acc0);
-      acc1 = mfma(a[t], w1[t], acc1);
+      acc0 = mfma(a[s][t], w0[s][t], acc0);
+      acc1 = mfma(a[s][t], w1[s][t], acc1);
     }
   }
 #pragma unroll
@@ -555,8 +609,8 @@ __global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict_
     const int mr = m0 + 4 * g + q;
     if (mr < B) {
       const size_t o = (size_t)mr * FLAT + n0 + r;
-      dn2[o] = n2[o] > 0.f ? acc0[q] : 0.f;
-      dn2[o + 16] = n2[o + 16] > 0.f ? acc1[q] : 0.f;
+      dn2[o] = mask0[q] > 0.f ? acc0[q] : 0.f;
+      dn2[o + 16] = mask1[q] > 0.f ? acc1[q] : 0.f;
     }
   }
 }

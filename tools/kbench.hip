@@ -63,12 +63,17 @@ int main(int argc, char** argv) {
   printf("conv2 single: %.2f us\n", time_us([&](hipEvent_t a, hipEvent_t b) {
     hipExtLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, a, b, 0, n1, w, w + 8192, n2, B); }, st, 20));
   chain("conv2", [&]() { hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, n1, w, w + 8192, n2, B); }, 200);
-  printf("dense1 single: %.2f us\n", time_us([&](hipEvent_t a, hipEvent_t b) {
-    hipExtLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 31) / 32, 22, 2), dim3(256), 0, st, a, b, 0, n2, pk, part, B, 11); }, st, 20));
-  chain("dense1", [&]() { hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 31) / 32, 22, 2), dim3(256), 0, st, n2, pk, part, B, 11); }, 200);
-  chain("conv1+conv2+dense1", [&]() {
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * 7), dim3(256), 0, st, x, w, w + 4096, n1, B);
-    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, n1, w, w + 8192, n2, B);
-    hipLaunchKernelGGL(dense1_fwd_kernel, dim3((B + 31) / 32, 22, 2), dim3(256), 0, st, n2, pk, part, B, 11); }, 100);
+  for (int mt : {1, 2}) {
+    const int nb = dense1_fwd_blocks(B, 22, mt);
+    auto l1 = [&](hipEvent_t a, hipEvent_t b) {
+      if (mt == 1) hipExtLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, a, b, 0, n2, pk, part, B, 22, 11);
+      else hipExtLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(nb), dim3(256), 0, st, a, b, 0, n2, pk, part, B, 22, 11); };
+    printf("dense1 MT=%d KS=22 blocks=%d single: %.2f us\n", mt, nb, time_us(l1, st, 20));
+    const int nb11 = dense1_fwd_blocks(B, 11, mt);
+    auto l2 = [&](hipEvent_t a, hipEvent_t b) {
+      if (mt == 1) hipExtLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(nb11), dim3(256), 0, st, a, b, 0, n2, pk, part, B, 11, 22);
+      else hipExtLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(nb11), dim3(256), 0, st, a, b, 0, n2, pk, part, B, 11, 22); };
+    printf("dense1 MT=%d KS=11 blocks=%d single: %.2f us\n", mt, nb11, time_us(l2, st, 20));
+  }
   return 0;
 }
