@@ -76,4 +76,5 @@ class Config:
     STATE_TRANSPORT = 'u8'              # 'u8': ship uint8 frames, convert on GPU; 'f32': ship f32 states
     SYNTHETIC_EPISODE_LENGTH = 1000
     TRAIN_ROWS_MAX = 0                  # capacity of one train call; 0 = derive from the batch knobs
+    ZERO_COPY = True                    # GPU gathers states straight from the registered shm transport
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often

@@ -180,6 +180,32 @@ class Network:
     def predict_single(self, x):
         return self.predict_p(x[None, :])[0]
 
+    # ---- zero-copy intake from the shared-memory transport --------------------------------------
+    def register_transport(self, transport):
+        """Pin the transport's segment for the GPU; afterwards predict_slots / train_rows gather from it."""
+        nat.check(self._lib.ga3c_net_register_host(self._h, C.c_void_p(transport.base), transport.nbytes),
+                  "ga3c_net_register_host")
+        self._transport_u8 = transport.state_bytes == nat.STATE_FLOATS
+
+    def predict_offsets(self, offsets):
+        """offsets: int64[B] byte offsets of the states inside the registered segment."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        b = offsets.size
+        p = np.empty((b, self.num_actions), dtype=np.float32)
+        v = np.empty((b,), dtype=np.float32)
+        nat.check(self._lib.ga3c_net_predict_gather(self._h, nat.ptr(offsets, nat.i64p), b, int(self._transport_u8),
+                                                    nat.ptr(p), nat.ptr(v), None), "ga3c_net_predict_gather")
+        return [p, v]
+
+    def train_offsets(self, offsets, y_r, a):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        y, a = nat.as_f32(y_r), nat.as_f32(a)
+        losses = np.empty(3, dtype=np.float32)
+        nat.check(self._lib.ga3c_net_train_gather(self._h, nat.ptr(offsets, nat.i64p), int(self._transport_u8), nat.ptr(y),
+                                                  nat.ptr(a), offsets.size, float(self.learning_rate), float(self.beta),
+                                                  nat.ptr(losses)), "ga3c_net_train_gather")
+        self.last_losses = losses
+
     # ---- training ----------------------------------------------------------------------------
     def train(self, x, y_r, a, x2=None, done=None, trainer_id=0):
         """x2, done and trainer_id are accepted and ignored, as in NetworkVP.py:254-257."""

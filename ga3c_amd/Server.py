@@ -33,6 +33,10 @@ class Server:
                                              Config.MAX_QUEUE_SIZE, Config.TIME_MAX + 1)
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
                                                              self.state_dim)
+        # let the GPU read states straight out of the transport's slots (no host gather, no staging copy)
+        self.zero_copy = bool(Config.ZERO_COPY) and hasattr(self.model, "register_transport")
+        if self.zero_copy:
+            self.model.register_transport(self.transport)
         if Config.LOAD_CHECKPOINT:
             try:
                 self.stats.episode_count.value = self.model.load()
@@ -84,12 +88,20 @@ class Server:
     # ---- training bookkeeping (Server.py:141-153) ----------------------------------------------
     def train_model(self, x_, r_, a_, x2, done, trainer_id):
         self.model.train(x_, r_, a_, x2, done, trainer_id)
+        self._count_train_step(x_.shape[0], x_, r_, a_)
+
+    def _count_train_step(self, rows, x_, r_, a_):
         self.training_step += 1
-        self.frame_counter += x_.shape[0]
+        self.frame_counter += rows
         self.stats.training_count.value += 1
         self.dynamic_adjustment.temporal_training_count += 1
         if Config.TENSORBOARD and self.stats.training_count.value % Config.TENSORBOARD_UPDATE_FREQUENCY == 0:
             self.model.log(x_, r_, a_, self.training_step)
+
+    def train_model_rows(self, row_offsets, r_, a_, trainer_id):
+        """train_model for rows that are still sitting in the transport (zero-copy intake)."""
+        self.model.train_offsets(row_offsets, r_, a_)
+        self._count_train_step(row_offsets.shape[0], None, r_, a_)
 
     def save_model(self):
         self.model.save(self.stats.episode_count.value)

@@ -33,16 +33,22 @@ class ThreadPredictor(Thread):
         # staging batch in pinned memory when the model offers it, so the H2D copy is a plain DMA
         alloc = getattr(self.server.model, "pinned_array", None)
         shape = (bmax, t.state_bytes)
-        staging = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
+        staging = None
+        if not getattr(self.server, "zero_copy", False):
+            staging = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
+        zero_copy = getattr(self.server, "zero_copy", False)
         while not self.exit_flag:
             size = t.pop_batch(ids, Config.QUEUE_TIMEOUT_MS)
             if size == 0:
                 continue
             if size < 0:
                 break                                   # transport shut down
-            np.take(t.agent_states, ids[:size], axis=0, out=staging[:size])
-            batch = staging[:size] if u8 else staging[:size].view(np.float32)
-            p, v = self.server.model.predict_p_and_v(batch.reshape((size,) + tuple(self.state_dim)))
+            if zero_copy:                               # the GPU gathers the states out of the slots itself
+                p, v = self.server.model.predict_offsets(t.state_offsets(ids[:size]))
+            else:
+                np.take(t.agent_states, ids[:size], axis=0, out=staging[:size])
+                batch = staging[:size] if u8 else staging[:size].view(np.float32)
+                p, v = self.server.model.predict_p_and_v(batch.reshape((size,) + tuple(self.state_dim)))
             t.respond(ids, size, np.ascontiguousarray(p, np.float32), np.ascontiguousarray(v, np.float32))
             self.batches += 1
             self.served += size

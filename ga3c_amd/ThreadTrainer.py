@@ -28,12 +28,17 @@ class ThreadTrainer(Thread):
         u8 = t.state_bytes == int(np.prod(state_dim))
         alloc = getattr(self.server.model, "pinned_array", None)
         shape = (cap, t.state_bytes)
-        x_stage = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
+        zero_copy = getattr(self.server, "zero_copy", False)
+        x_stage = None
+        if not zero_copy:
+            x_stage = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
+        off_stage = np.zeros(cap, np.int64)
         r_stage = np.zeros(cap, np.float32)
         a_stage = np.zeros(cap, np.int32)
         eye = np.eye(t.num_actions, dtype=np.float32)
         while not self.exit_flag:
             batch_size = 0
+            held = []                                   # zero-copy: slots stay ours until the GPU has read them
             while batch_size <= Config.TRAINING_MIN_BATCH_SIZE and not self.exit_flag:
                 slot = t.pop_rollout(Config.QUEUE_TIMEOUT_MS)
                 if slot == -3:
@@ -42,14 +47,24 @@ class ThreadTrainer(Thread):
                     return                              # transport shut down
                 rows = t.rows(slot)
                 states, returns, actions = t.rollout_views(slot)
-                x_stage[batch_size:batch_size + rows] = states[:rows]
                 r_stage[batch_size:batch_size + rows] = returns[:rows]
                 a_stage[batch_size:batch_size + rows] = actions[:rows]
-                t.release(slot)
+                if zero_copy:
+                    off_stage[batch_size:batch_size + rows] = t.rollout_row_offsets(slot, rows)
+                    held.append(slot)
+                else:
+                    x_stage[batch_size:batch_size + rows] = states[:rows]
+                    t.release(slot)
                 batch_size += rows
+            if batch_size and Config.TRAIN_MODELS and not self.exit_flag:
+                if zero_copy:
+                    self.server.train_model_rows(off_stage[:batch_size], r_stage[:batch_size],
+                                                 eye[a_stage[:batch_size]], self.id)
+                else:
+                    xb = x_stage[:batch_size] if u8 else x_stage[:batch_size].view(np.float32)
+                    self.server.train_model(xb.reshape((batch_size,) + state_dim), r_stage[:batch_size],
+                                            eye[a_stage[:batch_size]], None, None, self.id)
+            for slot in held:
+                t.release(slot)
             if self.exit_flag or batch_size == 0:
                 break
-            if Config.TRAIN_MODELS:
-                xb = x_stage[:batch_size] if u8 else x_stage[:batch_size].view(np.float32)
-                self.server.train_model(xb.reshape((batch_size,) + state_dim), r_stage[:batch_size],
-                                        eye[a_stage[:batch_size]], None, None, self.id)

@@ -27,8 +27,8 @@ class Transport:
         self.nbytes = self._lib.ga3c_shm_bytes(self._h)
         self.base = self._lib.ga3c_shm_base(self._h)
         self._raw = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.base), dtype=np.uint8)
-        off0 = self._lib.ga3c_shm_state_offset(self._h, 0)
-        stride = self._lib.ga3c_shm_agent_stride(self._h)
+        off0 = self.state_off0 = self._lib.ga3c_shm_state_offset(self._h, 0)
+        stride = self.agent_stride = self._lib.ga3c_shm_agent_stride(self._h)
         # [max_agents, state_bytes] strided view over every agent's state
         self.agent_states = np.lib.stride_tricks.as_strided(self._raw[off0:], shape=(self.max_agents, self.state_bytes),
                                                             strides=(stride, 1), writeable=True)
@@ -108,6 +108,13 @@ class Transport:
 
     def release(self, slot):
         nat.check_host(self._lib.ga3c_tq_release(self._h, slot), "ga3c_tq_release")
+
+    def state_offsets(self, ids):
+        """Byte offsets (into the segment) of the states of agents `ids` -- what the GPU gather consumes."""
+        return self.state_off0 + ids.astype(np.int64) * self.agent_stride
+
+    def rollout_row_offsets(self, slot, rows):
+        return self._ro_off0 + slot * self._ro_stride + np.arange(rows, dtype=np.int64) * self.state_bytes
 
     def ready_count(self):
         return self._lib.ga3c_tq_ready_count(self._h)

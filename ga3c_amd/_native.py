@@ -21,6 +21,7 @@ f64p = C.POINTER(C.c_double)
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
 i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
 
 
 class NetConfig(C.Structure):
@@ -51,6 +52,11 @@ HIP_SIGNATURES = {
     "ga3c_net_train_u8": (C.c_int, [C.c_void_p, u8p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_compute_grads": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32, C.c_float, f32p]),
     "ga3c_net_apply_grads": (C.c_int, [C.c_void_p, C.c_float]),
+    "ga3c_net_register_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "ga3c_net_unregister_host": (C.c_int, [C.c_void_p]),
+    "ga3c_net_predict_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, f32p, f32p, f32p]),
+    "ga3c_net_train_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, f32p, f32p, C.c_int32, C.c_float,
+                                        C.c_float, f32p]),
     "ga3c_net_upload": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32]),
     "ga3c_net_predict_resident": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_net_train_resident": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float]),

@@ -70,6 +70,8 @@ struct Lane {
   Fwd f;
   float* h_in = nullptr;    // pinned staging, max_batch states
   float* h_out = nullptr;   // pinned staging, p|v|z
+  int64_t* h_off = nullptr; // pinned: per-row byte offsets for gather_states_kernel
+  int64_t* d_off = nullptr;
   hipEvent_t read_done[2] = {nullptr, nullptr};
   bool dirty[2] = {false, false};   // read_done[i] recorded since theta[i] was last written (guarded by wmu)
 };
@@ -82,6 +84,8 @@ struct TrainLane {
         *dn2 = nullptr, *dn1 = nullptr, *slab2 = nullptr, *slab1 = nullptr, *losses = nullptr, *scales = nullptr;
   float* h_in = nullptr;    // pinned: x | y_r | a
   float* h_out = nullptr;   // pinned: p | v | z | losses
+  int64_t* h_off = nullptr;
+  int64_t* d_off = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -107,6 +111,9 @@ struct ga3c_net {
   int64_t step = 0;
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+  void* reg_host = nullptr;            // HIP-registered host segment (the shm transport) ...
+  uint8_t* reg_dev = nullptr;          // ... and the device-side address of its first byte
+  int64_t reg_bytes = 0;
   TensorTable tt;
 };
 
@@ -328,21 +335,59 @@ int read_losses(ga3c_net* net, float* losses) {
   return GA3C_OK;
 }
 
+// rows of a batch gathered from the registered host segment into x (device), on stream st
+int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off, int64_t* d_off, float* x,
+                  hipStream_t st) {
+  if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
+  if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
+  const int64_t sb = (int64_t)XS * (u8 ? 1 : 4);
+  for (int i = 0; i < B; ++i) {
+    if (offsets[i] < 0 || offsets[i] + sb > net->reg_bytes || (offsets[i] & 15))
+      return fail(GA3C_EINVAL, "row %d: offset %lld outside the registered segment or not 16-byte aligned", i, (long long)offsets[i]);
+    h_off[i] = offsets[i];
+  }
+  HIPCHK(hipMemcpyAsync(d_off, h_off, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (u8) hipLaunchKernelGGL(gather_states_kernel<true>, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, x, B);
+  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, x, B);
+  HIPCHK(hipGetLastError());
+  return GA3C_OK;
+}
+
+Lane* take_lane(ga3c_net* net) {
+  const unsigned start = net->rr.fetch_add(1);
+  for (size_t k = 0; k < net->lanes.size(); ++k) {
+    Lane* c = net->lanes[(start + k) % net->lanes.size()];
+    if (c->mu.try_lock()) return c;
+  }
+  Lane* L = net->lanes[start % net->lanes.size()];
+  L->mu.lock();
+  return L;
+}
+
+int finish_predict(ga3c_net* net, Lane* L, int B, float* p, float* v, float* z) {
+  const int A = net->A;
+  CHK(lane_forward(net, *L, B));
+  float* hp = L->h_out;
+  float* hv = hp + (size_t)net->maxB * A;
+  float* hz = hv + net->maxB;
+  HIPCHK(hipMemcpyAsync(hp, L->f.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  HIPCHK(hipMemcpyAsync(hv, L->f.v, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  HIPCHK(hipStreamSynchronize(L->st));
+  memcpy(p, hp, (size_t)B * A * sizeof(float));
+  memcpy(v, hv, (size_t)B * sizeof(float));
+  if (z) memcpy(z, hz, (size_t)B * A * sizeof(float));
+  return GA3C_OK;
+}
+
 int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float* v, float* z) {
   if (!net || !x || !p || !v) return fail(GA3C_EINVAL, "null argument");
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
-  // take any free lane, else wait on the next one in round-robin order
-  Lane* L = nullptr;
-  const unsigned start = net->rr.fetch_add(1);
-  for (size_t k = 0; k < net->lanes.size() && !L; ++k) {
-    Lane* c = net->lanes[(start + k) % net->lanes.size()];
-    if (c->mu.try_lock()) L = c;
-  }
-  if (!L) {
-    L = net->lanes[start % net->lanes.size()];
-    L->mu.lock();
-  }
+  Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   const int A = net->A;
   if (u8) {
@@ -366,18 +411,7 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
       HIPCHK(hipMemcpyAsync(L->f.x, L->h_in, nb, hipMemcpyHostToDevice, L->st));
     }
   }
-  CHK(lane_forward(net, *L, B));
-  float* hp = L->h_out;
-  float* hv = hp + (size_t)net->maxB * A;
-  float* hz = hv + net->maxB;
-  HIPCHK(hipMemcpyAsync(hp, L->f.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
-  HIPCHK(hipMemcpyAsync(hv, L->f.v, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, L->st));
-  if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
-  HIPCHK(hipStreamSynchronize(L->st));
-  memcpy(p, hp, (size_t)B * A * sizeof(float));
-  memcpy(v, hv, (size_t)B * sizeof(float));
-  if (z) memcpy(z, hz, (size_t)B * A * sizeof(float));
-  return GA3C_OK;
+  return finish_predict(net, L, B, p, v, z);
 }
 
 int sync_all(ga3c_net* net) {
@@ -465,6 +499,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     TRYHIP(hipHostMalloc((void**)&L->h_in, (size_t)maxB * XS * sizeof(float), hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
     for (int k = 0; k < 2; ++k) TRYHIP(hipEventCreateWithFlags(&L->read_done[k], hipEventDisableTiming));
+    TRYHIP(hipHostMalloc((void**)&L->h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
+    TRYHIP(hipMalloc((void**)&L->d_off, (size_t)maxB * sizeof(int64_t)));
   }
   TrainLane& t = net->tr;
   TRYHIP(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
@@ -485,6 +521,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   TRYHIP(hipHostMalloc((void**)&t.h_out, ((size_t)maxB * (2 * A + 1) + 4) * sizeof(float), hipHostMallocDefault));
   TRYHIP(hipEventCreate(&t.ev0));
   TRYHIP(hipEventCreate(&t.ev1));
+  TRYHIP(hipHostMalloc((void**)&t.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
+  TRYHIP(hipMalloc((void**)&t.d_off, (size_t)maxB * sizeof(int64_t)));
   TRYHIP(hipDeviceSynchronize());
 #undef TRY
 #undef TRYHIP
@@ -501,6 +539,8 @@ int ga3c_net_destroy(ga3c_net* net) {
     free_fwd(L->f);
     if (L->h_in) (void)hipHostFree(L->h_in);
     if (L->h_out) (void)hipHostFree(L->h_out);
+    if (L->h_off) (void)hipHostFree(L->h_off);
+    if (L->d_off) (void)hipFree(L->d_off);
     for (int k = 0; k < 2; ++k)
       if (L->read_done[k]) (void)hipEventDestroy(L->read_done[k]);
     if (L->st) (void)hipStreamDestroy(L->st);
@@ -512,6 +552,9 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (p) (void)hipFree(p);
   if (t.h_in) (void)hipHostFree(t.h_in);
   if (t.h_out) (void)hipHostFree(t.h_out);
+  if (t.h_off) (void)hipHostFree(t.h_off);
+  if (t.d_off) (void)hipFree(t.d_off);
+  if (net->reg_host) (void)hipHostUnregister(net->reg_host);
   if (t.ev0) (void)hipEventDestroy(t.ev0);
   if (t.ev1) (void)hipEventDestroy(t.ev1);
   if (t.st) (void)hipStreamDestroy(t.st);
@@ -632,6 +675,58 @@ int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const f
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
   CHK(stage_train_inputs(net, x, true, y_r, a, batch));
+  CHK(train_grads(net, batch, beta));
+  CHK(train_apply(net, learning_rate));
+  return read_losses(net, losses);
+}
+
+int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes) {
+  if (!net || !base || bytes < 16) return fail(GA3C_EINVAL, "bad argument");
+  if (net->reg_host) return fail(GA3C_ESTATE, "a host segment is already registered");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  HIPCHK(hipHostRegister(base, (size_t)bytes, hipHostRegisterMapped));
+  void* dev = nullptr;
+  hipError_t e = hipHostGetDevicePointer(&dev, base, 0);
+  if (e != hipSuccess) {
+    (void)hipHostUnregister(base);
+    return fail(GA3C_EHIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+  }
+  net->reg_host = base;
+  net->reg_dev = (uint8_t*)dev;
+  net->reg_bytes = bytes;
+  return GA3C_OK;
+}
+
+int ga3c_net_unregister_host(ga3c_net* net) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  if (!net->reg_host) return GA3C_OK;
+  HIPCHK(hipSetDevice(net->cfg.device));
+  CHK(sync_all(net));
+  HIPCHK(hipHostUnregister(net->reg_host));
+  net->reg_host = nullptr;
+  net->reg_dev = nullptr;
+  net->reg_bytes = 0;
+  return GA3C_OK;
+}
+
+int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch, int32_t u8, float* p, float* v,
+                            float* z) {
+  if (!net || !offsets || !p || !v) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  Lane* L = take_lane(net);
+  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  CHK(launch_gather(net, offsets, batch, u8 != 0, L->h_off, L->d_off, L->f.x, L->st));
+  return finish_predict(net, L, batch, p, v, z);
+}
+
+int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
+                          int32_t batch, float learning_rate, float beta, float* losses) {
+  if (!net || !offsets || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  TrainLane& t = net->tr;
+  CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.d_off, t.f.x, t.st));
+  CHK(stage_train_inputs(net, nullptr, false, y_r, a, batch));
   CHK(train_grads(net, batch, beta));
   CHK(train_apply(net, learning_rate));
   return read_losses(net, losses);

@@ -66,6 +66,34 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restric
   }
 }
 
+// Gather of states straight out of the (HIP-registered) shared-memory transport: row b of the batch is the
+// 28,224 uint8 frames (or 28,224 f32) found at host_base + offsets[b]; written as f32 NHWC into x[b].
+// 16-byte reads over PCIe, one pass, conversion `k/128 - 1` fused.
+template <bool U8>
+__global__ __launch_bounds__(256) void gather_states_kernel(const uint8_t* __restrict__ host_base,
+                                                            const int64_t* __restrict__ offsets, float* __restrict__ x,
+                                                            int B) {
+  constexpr int CHUNKS = U8 ? XS / 16 : XS / 4;     // 16-byte chunks per state
+  const int64_t total = (int64_t)B * CHUNKS;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / CHUNKS), c = (int)(i - (int64_t)b * CHUNKS);
+    const uint8_t* src = host_base + offsets[b] + (size_t)c * 16;
+    if (U8) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(src);
+      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
+      float* dst = x + (size_t)b * XS + (size_t)c * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 o = {(float)(wds[k] & 255u) * 0.0078125f - 1.0f, (float)((wds[k] >> 8) & 255u) * 0.0078125f - 1.0f,
+                   (float)((wds[k] >> 16) & 255u) * 0.0078125f - 1.0f, (float)(wds[k] >> 24) * 0.0078125f - 1.0f};
+        *reinterpret_cast<f32x4*>(dst + 4 * k) = o;
+      }
+    } else {
+      *reinterpret_cast<f32x4*>(x + (size_t)b * XS + (size_t)c * 4) = *reinterpret_cast<const f32x4*>(src);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ conv1 forward
 // n1[m][o] = relu(b1[o] + sum_k patch(m)[k] W1[k][o]),  m = (b*21+i)*21+j, k = (u*8+v)*4+c.
 // Implicit GEMM M = B*441, K = 256, N = 16.  im2col re-reads every input pixel 4x; served from L2 that

@@ -56,7 +56,7 @@ typedef struct ga3c_net_config {
 const char* ga3c_last_error(void);
 int ga3c_device_count(int32_t* count);
 
-/* Network.__init__ / session teardown.  Weights are zero until ga3c_net_set_params. */
+/* Network.__init__ / session teardown.  Weights are zero until ga3c_net_set_arena(which = 0). */
 int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out);
 int ga3c_net_destroy(ga3c_net* net);
 
@@ -110,6 +110,18 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
 /* Activations / per-sample gradients of the last resident or train-lane step, for parity tests:
  * name in {"n1","n2","d1","z","p","v","dz","dv","dd1","dn2","dn1"}. */
 int ga3c_net_fetch(ga3c_net* net, const char* name, float* out, int64_t count);
+
+/* Zero-copy intake from the shared-memory transport (include/ga3c_host.h): register the whole segment
+ * once (hipHostRegister), then a batch is described by one byte offset per row into that segment and the GPU
+ * gathers the states itself (uint8 -> f32 fused) -- no host-side gather, no staging copy.  Offsets must be
+ * 16-byte aligned; u8 != 0 means rows are 28,224 uint8 frames, else 28,224 f32.
+ * Replaces the feed_dict copy of ThreadPredictor.py:57-58 / ThreadTrainer.py:52-59 + NetworkVP.py:252,257. */
+int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes);
+int ga3c_net_unregister_host(ga3c_net* net);
+int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch, int32_t u8, float* p, float* v,
+                            float* z);
+int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
+                          int32_t batch, float learning_rate, float beta, float* losses);
 
 /* Pinned host memory for staging arrays (ThreadPredictor.py:46-47 `states`), so that
  * predict/train copy by DMA without an intermediate host copy. */

@@ -8,10 +8,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(180)
-def test_engine_trains_on_gpu(tmp_path, monkeypatch):
+@pytest.mark.parametrize("zero_copy", [True, False])
+def test_engine_trains_on_gpu(tmp_path, monkeypatch, zero_copy):
     import ga3c_amd  # noqa: F401
     from Config import Config
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(Config, "ZERO_COPY", zero_copy)
     saved = {k: getattr(Config, k) for k in ("AGENTS", "PREDICTORS", "TRAINERS", "SYNTHETIC_EPISODE_LENGTH", "TIME_MAX",
                                              "DYNAMIC_SETTINGS", "SAVE_MODELS", "TRAINING_MIN_BATCH_SIZE", "NUM_ACTIONS",
                                              "PREDICTION_BATCH_SIZE")}
@@ -22,6 +24,7 @@ def test_engine_trains_on_gpu(tmp_path, monkeypatch):
     try:
         from Server import Server
         srv = Server(max_agents=8)
+        assert srv.zero_copy == zero_copy
         before = srv.model.get_arena(0)
         srv.main(max_seconds=5)
         after = srv.model.get_arena(0)
@@ -41,3 +44,46 @@ def test_engine_trains_on_gpu(tmp_path, monkeypatch):
     finally:
         for k, v in saved.items():
             setattr(Config, k, v)
+
+
+def test_gather_from_registered_transport_is_bit_identical_to_host_path():
+    """ga3c_net_predict_gather / train_gather read the states out of the pinned shm segment themselves; the
+    result must equal feeding the same bytes through the host-buffer entry points."""
+    import ga3c_amd  # noqa: F401
+    import Transport as tp
+    from NetworkVP import Network
+    t = tp.Transport.create(tp.unique_name("t_zc"), 40, 6, 84 * 84 * 4, 8, 6)
+    net = Network("gpu:0", "zc", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
+    try:
+        net.register_transport(t)
+        rng = np.random.default_rng(12)
+        frames = rng.integers(0, 256, size=(40, 84 * 84 * 4), dtype=np.uint8)
+        t.agent_states[:] = frames
+        ids = rng.permutation(40)[:33].astype(np.uint32)
+        p1, v1 = net.predict_offsets(t.state_offsets(ids))
+        p2, v2 = net.predict_p_and_v(frames[ids].reshape(-1, 84, 84, 4))
+        assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+        # training rows out of two rollout slots
+        offs, xs = [], []
+        for slot, rows in ((3, 6), (5, 4)):
+            states, _, _ = t.rollout_views(slot)
+            states[:rows] = rng.integers(0, 256, size=(rows, 84 * 84 * 4), dtype=np.uint8)
+            offs.append(t.rollout_row_offsets(slot, rows))
+            xs.append(states[:rows].copy())
+        offs, xs = np.concatenate(offs), np.concatenate(xs).reshape(-1, 84, 84, 4)
+        y = rng.uniform(-1, 1, 10)
+        a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, 10)]
+        theta0 = net.get_arena(0)
+        net.learning_rate, net.beta = 3e-4, 0.01
+        net.train_offsets(offs, y, a)
+        got = net.get_arena(0)
+        net.set_arena(0, theta0)
+        net.set_arena(1, np.ones_like(theta0))
+        net.train(xs, y, a)
+        assert np.array_equal(got, net.get_arena(0))
+        with pytest.raises(RuntimeError):
+            net.predict_offsets(np.array([t.nbytes], dtype=np.int64))       # outside the registered segment
+    finally:
+        net.close()
+        t.shutdown()
+        t.close()
