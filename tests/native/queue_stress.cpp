@@ -1,0 +1,94 @@
+// Multi-threaded stress of the shared-memory transport (include/ga3c_host.h), built with
+// -fsanitize=thread by tests/test_host_tsan.py.  Agents and predictors run as threads of ONE process on
+// one segment: the protocol is the same as across processes, and TSAN sees every access.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <unistd.h>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/ga3c_host.h"
+
+static std::atomic<int> failures{0};
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s line %d\n", #c, __LINE__); failures++; } } while (0)
+
+int main(int argc, char** argv) {
+  const int n_agents = 12, n_pred = 3, rounds = argc > 1 ? std::atoi(argv[1]) : 1500, n_act = 6;
+  ga3c_shm_config cfg;
+  std::memset(&cfg, 0, sizeof cfg);
+  cfg.max_agents = n_agents; cfg.num_actions = n_act; cfg.state_bytes = 64; cfg.train_slots = 4; cfg.train_rows = 6;
+  ga3c_shm* shm = nullptr;
+  char name[64];
+  std::snprintf(name, sizeof name, "/ga3c_tsan_%d", (int)getpid());
+  REQUIRE(ga3c_shm_create(name, &cfg, &shm) == 0);
+  std::atomic<long> served{0}, trained_rows{0}, produced_rows{0};
+  std::vector<std::thread> th;
+  for (int p = 0; p < n_pred; ++p)
+    th.emplace_back([&] {
+      uint32_t ids[8];
+      float pbuf[8 * 6], vbuf[8];
+      for (;;) {
+        const int n = ga3c_pq_pop_batch(shm, ids, 8, 50);
+        if (n == GA3C_H_ECLOSED) return;
+        if (n <= 0) continue;
+        for (int i = 0; i < n; ++i) {
+          const unsigned char* st = (const unsigned char*)ga3c_pq_state_ptr(shm, (int)ids[i]);
+          int tag;
+          std::memcpy(&tag, st, 4);
+          vbuf[i] = (float)tag;
+          for (int o = 0; o < n_act; ++o) pbuf[i * n_act + o] = (float)(tag % 7 + o);
+        }
+        REQUIRE(ga3c_pq_respond(shm, ids, n, pbuf, vbuf) == 0);
+        served += n;
+      }
+    });
+  std::thread trainer([&] {
+    for (;;) {
+      const int slot = ga3c_tq_pop(shm, 50);
+      if (slot == GA3C_H_ECLOSED) return;
+      if (slot < 0) continue;
+      const int rows = ga3c_tq_rows(shm, slot);
+      const float* ret = ga3c_tq_returns(shm, slot);
+      const int32_t* act = ga3c_tq_actions(shm, slot);
+      for (int i = 0; i < rows; ++i) REQUIRE((int)ret[i] == act[i] * 3);
+      trained_rows += rows;
+      REQUIRE(ga3c_tq_release(shm, slot) == 0);
+    }
+  });
+  std::vector<std::thread> agents;
+  for (int a = 0; a < n_agents; ++a)
+    agents.emplace_back([&, a] {
+      float p[6], v;
+      for (int k = 0; k < rounds; ++k) {
+        const int tag = a * 100000 + k;
+        std::memcpy(ga3c_pq_state_ptr(shm, a), &tag, 4);
+        REQUIRE(ga3c_pq_submit(shm, a) == 0);
+        int rc;
+        while ((rc = ga3c_pq_wait(shm, a, p, &v, 100)) == GA3C_H_ETIMEOUT) {}
+        REQUIRE(rc == 0);
+        REQUIRE((int)v == tag);
+        REQUIRE((int)p[2] == tag % 7 + 2);
+        if (k % 5 == 4) {                       // ship a rollout
+          int slot;
+          while ((slot = ga3c_tq_acquire(shm, 100)) == GA3C_H_ETIMEOUT) {}
+          REQUIRE(slot >= 0);
+          const int rows = 1 + (k % 6);
+          for (int i = 0; i < rows; ++i) { ga3c_tq_actions(shm, slot)[i] = a + i; ga3c_tq_returns(shm, slot)[i] = (float)((a + i) * 3); }
+          REQUIRE(ga3c_tq_commit(shm, slot, rows) == 0);
+          produced_rows += rows;
+        }
+      }
+    });
+  for (auto& t : agents) t.join();
+  while (trained_rows.load() < produced_rows.load()) std::this_thread::yield();
+  ga3c_shm_shutdown(shm);
+  for (auto& t : th) t.join();
+  trainer.join();
+  REQUIRE(served.load() == (long)n_agents * rounds);
+  REQUIRE(trained_rows.load() == produced_rows.load());
+  ga3c_shm_close(shm, 1);
+  std::printf("served %ld predictions, %ld rollout rows, failures %d\n", served.load(), trained_rows.load(), failures.load());
+  return failures.load() ? 1 : 0;
+}

@@ -1,0 +1,107 @@
+"""CPU tests of the pieces around the hot path: ThreadDynamicAdjustment (reference
+ThreadDynamicAdjustment.py:53-144), the two return modes of ProcessAgent, convert_data dtypes."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture()
+def cfg():
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    saved = {k: v for k, v in vars(Config).items() if k.isupper()}
+    yield Config
+    for k, v in saved.items():
+        setattr(Config, k, v)
+
+
+class _Stats:
+    class _V:
+        value = 0
+
+    def __init__(self):
+        self.trainer_count, self.predictor_count, self.agent_count = self._V(), self._V(), self._V()
+
+
+class _Server:
+    def __init__(self):
+        self.trainers, self.predictors, self.agents = [], [], []
+        self.stats = _Stats()
+        self.max_agents = 64
+        self.log = []
+
+    def add_trainer(self): self.trainers.append(0); self.log.append("+T")
+    def remove_trainer(self): self.trainers.pop(); self.log.append("-T")
+    def add_predictor(self): self.predictors.append(0); self.log.append("+P")
+    def remove_predictor(self): self.predictors.pop(); self.log.append("-P")
+    def add_agent(self): self.agents.append(0); self.log.append("+A")
+    def remove_agent(self): self.agents.pop(); self.log.append("-A")
+
+
+def test_dynamic_adjustment_creates_and_resizes_workers(cfg):
+    from ThreadDynamicAdjustment import ThreadDynamicAdjustment
+    cfg.TRAINERS, cfg.PREDICTORS, cfg.AGENTS, cfg.DYNAMIC_SETTINGS = 2, 3, 5, False
+    srv = _Server()
+    da = ThreadDynamicAdjustment(srv)
+    da.run()                                           # not enabled: create the initial workers and return
+    assert (len(srv.trainers), len(srv.predictors), len(srv.agents)) == (2, 3, 5)
+    assert (srv.stats.trainer_count.value, srv.stats.predictor_count.value, srv.stats.agent_count.value) == (2, 3, 5)
+    da.trainer_count, da.predictor_count, da.agent_count = 1, 4, 3
+    da.enable_disable_components()
+    assert (len(srv.trainers), len(srv.predictors), len(srv.agents)) == (1, 4, 3)
+    # agents ARE removed when the target drops (the reference's branch at :79 can never run)
+    assert srv.log.count("-A") == 2
+
+
+def test_dynamic_adjustment_random_walk_bounds(cfg):
+    from ThreadDynamicAdjustment import ThreadDynamicAdjustment
+    cfg.TRAINERS, cfg.PREDICTORS, cfg.AGENTS = 1, 1, 1
+    da = ThreadDynamicAdjustment(_Server())
+    np.random.seed(0)
+    seen = set()
+    for _ in range(200):
+        before = (da.trainer_count, da.predictor_count, da.agent_count)
+        da.random_walk()
+        after = (da.trainer_count, da.predictor_count, da.agent_count)
+        assert all(a >= 1 for a in after) and all(abs(a - b) <= 1 for a, b in zip(after, before))
+        assert da.agent_count <= 64
+        seen.add(after)
+    assert len(seen) > 10
+
+
+def _experiences(rewards):
+    from Experience import Experience
+    s = np.zeros((84, 84, 4), np.uint8)
+    return [Experience(s, i % 3, np.full(3, 1 / 3, np.float32), r, s, False) for i, r in enumerate(rewards)]
+
+
+def test_return_modes(cfg):
+    from ProcessAgent import ProcessAgent
+    import ga3c_oracle as o
+    rewards = [0.0, 0.5, -3.0, 2.0, 1.0]
+    cfg.RETURN_MODE = 'fork'
+    out = ProcessAgent._accumulate_rewards(_experiences(rewards), 0.99, 1.0)
+    assert [e.reward for e in out] == o.accumulate_rewards_fork(rewards, 0.99, 1.0) and len(out) == 5
+    cfg.USE_INTERMEDIATE_REWARD = True                  # the fork then writes nothing back (ProcessAgent.py:79-82)
+    out = ProcessAgent._accumulate_rewards(_experiences(rewards), 0.99, 1.0)
+    assert [e.reward for e in out] == rewards
+    cfg.USE_INTERMEDIATE_REWARD = False
+    cfg.RETURN_MODE = 'nstep'                           # upstream GA3C: clip, bootstrap, drop the last row
+    out = ProcessAgent._accumulate_rewards(_experiences(rewards), 0.99, 0.25)
+    assert [e.reward for e in out] == o.returns_nstep(rewards, 0.99, 0.25) and len(out) == 4
+    r = 0.25
+    for t in (3, 2, 1, 0):
+        r = 0.99 * r + min(max(rewards[t], -1), 1)
+        assert out[t].reward == r
+
+
+def test_convert_data_dtypes_match_reference(cfg, golden_dir):
+    import json, os
+    from ProcessAgent import ProcessAgent
+    want = json.load(open(os.path.join(golden_dir, "returns_fork.json")))["convert_data_dtypes"]
+    agent = ProcessAgent.__new__(ProcessAgent)
+    agent.num_actions = 3
+    x_, r_, a_, x2_, done_ = agent.convert_data(_experiences([0.0, 1.0, -1.0]))
+    got = dict(x_=str(x_.dtype), r_=str(r_.dtype), a_=str(a_.dtype), x2_=str(x2_.dtype), done_=str(done_.dtype))
+    assert got == want
+    assert x_.shape == (3, 84, 84, 4) and a_.shape == (3, 3) and np.all(a_.sum(axis=1) == 1)
+    assert np.all(x_ == -1.0)                           # uint8 0 -> 0/128 - 1

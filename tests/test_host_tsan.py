@@ -1,0 +1,24 @@
+"""Race detection for the C transport (the reference has none): the lock-free rings, the
+futex hand-offs and the rollout slot recycling are stressed under ThreadSanitizer (CPU build only)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_transport_stress_is_sanitizer_clean(tmp_path, sanitizer):
+    exe = str(tmp_path / "queue_stress")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-pthread",
+           os.path.join(ROOT, "tests", "native", "queue_stress.cpp"), os.path.join(ROOT, "ga3c_amd", "csrc", "ga3c_host.cpp"),
+           "-o", exe, "-lrt"]
+    subprocess.check_call(cmd)
+    run = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=240)
+    if sanitizer == "thread" and "FATAL: ThreadSanitizer" in run.stderr and "unexpected memory mapping" in run.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "WARNING: ThreadSanitizer" not in run.stderr and "ERROR: AddressSanitizer" not in run.stderr, run.stderr
+    assert "failures 0" in run.stdout
