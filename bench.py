@@ -8,7 +8,10 @@ frames, NetworkVP) on N MI355X of one node.
 
 A step is one pass of the hot path over one batch that is already resident in HBM:
   predict leg (the headline `value`): one ThreadPredictor batch (BASELINE.json configs[1]:
-      batch = 128 states) through the HIP NetworkVP forward -> p, v;
+      batch = 128 states) through the HIP NetworkVP forward -> p, v.  The K steps are dealt round-robin to
+      NP = 2 prediction lanes, i.e. the reference's default Config.PREDICTORS = 2 predictor threads
+      (Config.py:57, README.md:28-32 "NP: 2"), each lane with its own HIP stream and workspace exactly as
+      ThreadPredictor uses them; the single-lane figure is reported beside it under "predict_lanes";
   train leg (reported under "train"): one ThreadTrainer batch (configs[2]: 128 rows) through forward,
       loss, backward, RCCL all-reduce of the gradient arena when N > 1, RMSProp.
 Per-GPU work is fixed as N grows (weak scaling); predictions need no collective.
@@ -40,6 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--actions", type=int, default=6)
+    ap.add_argument("--predictors", type=int, default=2, help="prediction lanes the K predict steps are dealt to (Config.PREDICTORS)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length; 0 disables it")
     ap.add_argument("--e2e-seconds", type=float, default=8.0,
                     help="also run the whole engine (agent processes -> transport -> predictor/trainer threads) this long; 0 disables")
@@ -71,7 +75,8 @@ def main():
 
     B, A, K, W = args.batch, args.actions, args.steps, args.warmup
     Config.PREDICTION_BATCH_SIZE = B
-    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=1)
+    NP = max(1, args.predictors)
+    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=max(NP, 3))
     lib, h = net._lib, net._h
 
     import DataParallel
@@ -90,11 +95,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode, steps):
+    def timed(mode, steps, lanes=0):
         ev_ms = nat.C.c_float()
         barrier_sync()
         t0 = time.perf_counter()
-        nat.check(lib.ga3c_net_time_resident(h, mode, B, steps, lr, beta, nat.C.byref(ev_ms)), "time_resident")
+        if lanes:
+            nat.check(lib.ga3c_net_time_predict_lanes(h, B, steps, lanes, nat.C.byref(ev_ms)), "time_predict_lanes")
+        else:
+            nat.check(lib.ga3c_net_time_resident(h, mode, B, steps, lr, beta, nat.C.byref(ev_ms)), "time_resident")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if world > 1:
@@ -108,7 +116,11 @@ def main():
     for mode in (0, 1):
         if W > 0:
             nat.check(lib.ga3c_net_time_resident(h, mode, B, W, lr, beta, nat.C.byref(ev_ms)), "warmup")
-    pred_s, pred_ev_ms = timed(0, K)
+    if W > 0:
+        nat.check(lib.ga3c_net_time_predict_lanes(h, B, W, NP, nat.C.byref(ev_ms)), "warmup")
+    pred_s, _ = timed(0, K, lanes=NP)
+    one_s, pred_ev_ms = timed(0, K)
+    three_s, _ = timed(0, K, lanes=3)
     train_s, train_ev_ms = timed(1, K)
 
     out = None
@@ -120,9 +132,11 @@ def main():
             "steps": K, "warmup": W, "ms_per_step": pred_s / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PongDeterministic-v4 84x84x4 stacked frames, NetworkVP forward, "
-                                   "predictor batch=%d per GPU, A=%d (BASELINE configs[1])" % (B, A),
+                                   "predictor batch=%d, NP=%d predictor lanes per GPU, A=%d (BASELINE configs[1])" % (B, NP, A),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "inputs": "resident in HBM (f32 NHWC), outputs p,v left in HBM"},
+            "predict_lanes": {"1": world * K * B / one_s, str(NP): pps, "3": world * K * B / three_s,
+                              "unit": "predictions/s", "note": "same K steps dealt to 1 / NP / 3 prediction lanes"},
             "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
                       "ms_per_step": train_s / K * 1e3, "rows_per_step": world * B,
                       "trained_samples_per_sec": world * K * B / train_s,

@@ -62,6 +62,7 @@ HIP_SIGNATURES = {
     "ga3c_net_train_resident": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float]),
     "ga3c_net_sync": (C.c_int, [C.c_void_p]),
     "ga3c_net_time_resident": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, f32p]),
+    "ga3c_net_time_predict_lanes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, f32p]),
     "ga3c_net_time_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, f32p]),
     "ga3c_net_fetch": (C.c_int, [C.c_void_p, C.c_char_p, f32p, C.c_int64]),
     "ga3c_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),

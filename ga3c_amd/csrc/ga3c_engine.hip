@@ -793,6 +793,32 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
   return GA3C_OK;
 }
 
+int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float* elapsed_ms) {
+  // `iters` resident prediction steps dealt round-robin to `nlanes` prediction lanes (= NP predictor threads, each
+  // with its own stream and workspace); every lane holds a copy of the batch uploaded with ga3c_net_upload.
+  if (!net || !elapsed_ms) return fail(GA3C_EINVAL, "null argument");
+  if (iters < 1 || nlanes < 1 || nlanes > (int)net->lanes.size()) return fail(GA3C_EINVAL, "bad iters/nlanes");
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "bad batch");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(sync_all(net));
+  for (int l = 0; l < nlanes; ++l)
+    HIPCHK(hipMemcpy(net->lanes[l]->f.x, net->tr.f.x, (size_t)batch * XS * sizeof(float), hipMemcpyDeviceToDevice));
+  int idx;
+  {
+    std::shared_lock<std::shared_mutex> lk(net->wmu);
+    idx = net->cur;
+  }
+  const auto h0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) {
+    Lane* L = net->lanes[i % nlanes];
+    CHK(launch_forward(net, L->f, idx, batch, L->st, false, nullptr, 0.f));
+  }
+  for (int l = 0; l < nlanes; ++l) HIPCHK(hipStreamSynchronize(net->lanes[l]->st));
+  *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  return GA3C_OK;
+}
+
 int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32_t iters, float* elapsed_ms) {
   // Each launch carries its own start/stop events (hipExtLaunchKernelGGL), so the sum is pure kernel
   // execution time on the train lane's stream, without launch gaps.  Buffers hold whatever the last

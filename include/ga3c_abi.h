@@ -103,6 +103,9 @@ int ga3c_net_sync(ga3c_net* net);
  * events recorded on the stream the kernels run on; returns the elapsed milliseconds. */
 int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t iters,
                            float learning_rate, float beta, float* elapsed_ms);
+/* `iters` resident prediction steps dealt round-robin over `nlanes` prediction lanes (the NP predictor threads of
+ * Config.PREDICTORS, each with its own HIP stream); host wall-clock from first launch to all lanes drained. */
+int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float* elapsed_ms);
 /* Same bracket around ONE kernel of the step (name as in DESIGN.md, e.g. "conv1_fwd"). */
 int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32_t iters,
                          float* elapsed_ms);
