@@ -198,17 +198,21 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   HeadBwdArgs hb;
   hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
   hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV; hb.g_bv = g + OFF_BV; hb.losses = t.losses;
-  hipLaunchKernelGGL(dense1_dw_kernel, dim3(FLAT / 32 + A + 2, 2), dim3(256), 0, st, t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD,
-                     B, hb);
-  hipLaunchKernelGGL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), dim3(256), 0, st, t.dd1,
-                     th + OFF_WD, t.f.n2, t.dn2, B);
-  const int nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
-  hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
   {
+    Dense1BwdArgs d;
+    d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
+    d.hb = hb; d.dw_gx = FLAT / 32 + A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
+    const int dx_blocks = d.dx_gx * (((B + 15) / 16 + 3) / 4);
+    hipLaunchKernelGGL(dense1_bwd_kernel, dim3(d.dw_blocks + dx_blocks), dim3(256), 0, st, d);
+  }
+  const int nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
+  {
+    Conv2BwdArgs c;
+    c.n1 = t.f.n1; c.dn2 = t.dn2; c.w2 = th + OFF_W2; c.slab2 = t.slab2; c.dn1 = t.dn1; c.B = B;
+    c.dw_gx = nch2; c.dw_blocks = 4 * nch2;
     const int nt = (B * P2 + 15) / 16;
-    int blocks = (nt + 3) / 4;
-    if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(conv2_dx_kernel, dim3(blocks, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+    c.dx_gx = (nt + 3) / 4 > 256 ? 256 : (nt + 3) / 4;
+    hipLaunchKernelGGL(conv2_bwd_kernel, dim3(c.dw_blocks + 4 * c.dx_gx), dim3(256), 0, st, c);
   }
   const int nch1 = B * 7 < 512 ? B * 7 : 512;  // workgroups = partial slabs
   hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch1), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, B * 7);
@@ -864,6 +868,36 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       TL(dense1_dw_kernel, dim3(FLAT / 32 + net->A + 2, 2), t.f.n2, t.dd1, g + OFF_WD, g + OFF_BD, B, hb);
     } else if (k == "dense1_dx") {
       TL(dense1_dx_kernel, dim3(FLAT / 32, ((B + 15) / 16 + 3) / 4), t.dd1, th + OFF_WD, t.f.n2, t.dn2, B);
+    } else if (k == "dense1_bwd") {
+      Dense1BwdArgs d;
+      d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
+      d.hb.B = B; d.hb.A = net->A; d.hb.d1 = t.f.d1; d.hb.dz = t.dz; d.hb.dv = t.dv; d.hb.lossrow = t.lossrow;
+      d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
+      d.dw_gx = FLAT / 32 + net->A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
+      TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 15) / 16 + 3) / 4)), d);
+    } else if (k == "conv2_bwd") {
+      Conv2BwdArgs c;
+      c.n1 = t.f.n1; c.dn2 = t.dn2; c.w2 = th + OFF_W2; c.slab2 = t.slab2; c.dn1 = t.dn1; c.B = B;
+      c.dw_gx = B < 256 ? B : 256; c.dw_blocks = 4 * c.dw_gx;
+      const int nt = (B * P2 + 15) / 16;
+      c.dx_gx = (nt + 3) / 4 > 256 ? 256 : (nt + 3) / 4;
+      TL(conv2_bwd_kernel, dim3(c.dw_blocks + 4 * c.dx_gx), c);
+    } else if (k == "heads") {
+      HeadArgs h;
+      memset(&h, 0, sizeof h);
+      const int ks = dense_ks(B);
+      h.part = t.f.part; h.ks = ks; h.B = B; h.A = net->A;
+      h.bd = th + OFF_BD; h.wv = th + OFF_WV; h.bv = th + OFF_BV; h.wp = th + OFF_WP; h.bp = th + off_bp(net->A);
+      h.d1 = t.f.d1; h.z = t.f.z; h.p = t.f.p; h.v = t.f.v;
+      h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
+      if (net->A <= 8) TL((heads_kernel<false, 8>), dim3((B + 3) / 4), h);
+      else if (net->A <= 24) TL((heads_kernel<false, 24>), dim3((B + 3) / 4), h);
+      else TL((heads_kernel<false, 64>), dim3((B + 3) / 4), h);
+    } else if (k == "slab_reduce") {
+      const int nch1 = B * 7 < 512 ? B * 7 : 512, nch2 = B < 256 ? B : 256;
+      SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
+      SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
+      hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2);
     } else if (k == "rmsprop") {
       const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
       TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->cur], net->ms, net->mom, net->grad, net->n,

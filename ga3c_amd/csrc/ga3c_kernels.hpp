@@ -520,16 +520,16 @@ __device__ __forceinline__ void heads_bwd_role(const HeadBwdArgs& h, int role) {
 // grid.x = 121 row blocks, grid.y = 2, wave -> 32-column group (grid.y*4 + wave).
 // Row block 0 also produces dbd[n] = sum_b dd1[b][n].  Blocks with blockIdx.x >= 121 (grid.y == 0 only) carry the
 // head weight gradients and the loss sums (heads_bwd_role).
-__global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dd1,
+__device__ __forceinline__ void dense1_dw_body(const float* __restrict__ flat, const float* __restrict__ dd1,
                                                         float* __restrict__ g_wd, float* __restrict__ g_bd, int B,
-                                                        HeadBwdArgs hb) {
-  if (blockIdx.x >= FLAT / 32) {   // block-uniform
-    if (blockIdx.y == 0) heads_bwd_role(hb, blockIdx.x - FLAT / 32);
+                                                        HeadBwdArgs hb, int bx, int by, int gx) {
+  if (bx >= FLAT / 32) {   // block-uniform
+    if (by == 0) heads_bwd_role(hb, bx - FLAT / 32);
     return;
   }
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 32;
-  const int n0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 32;
+  const int m0 = bx * 32;
+  const int n0 = (by * 4 + (threadIdx.x >> 6)) * 32;
   f32x4 acc[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
   float bs0 = 0.f, bs1 = 0.f;
   const int nsteps = (B + 15) >> 4;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict_
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         g_wd[(size_t)(m0 + mi * 16 + 4 * g + q) * HID + n0 + ni * 16 + r] = acc[mi][ni][q];
-  if (blockIdx.x == 0) {
+  if (bx == 0) {
     bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
     bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
     if (g == 0) {
@@ -596,11 +596,11 @@ __global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict_
 // ------------------------------------------------------------------ dense1 backward: dn2 = (dd1 Wd^T) * 1[n2>0]
 // M = B, N = 3872, K = 256.  Both operands are k-contiguous (16-byte loads).  Wave tile 16 x 32.
 // grid.x = 121 column blocks of 32... each block's 4 waves take 4 consecutive m-tiles; grid.y covers the rest.
-__global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict__ dd1, const float* __restrict__ wd,
-                                                        const float* __restrict__ n2, float* __restrict__ dn2, int B) {
+__device__ __forceinline__ void dense1_dx_body(const float* __restrict__ dd1, const float* __restrict__ wd,
+                                                        const float* __restrict__ n2, float* __restrict__ dn2, int B, int bx, int by, int gx) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 32;
-  const int m0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * 16;
+  const int n0 = bx * 32;
+  const int m0 = (by * 4 + (threadIdx.x >> 6)) * 16;
   if (m0 >= B) return;   // wave-uniform
   const int row = m0 + r;
   const bool valid = row < B;
@@ -654,13 +654,13 @@ constexpr int SLAB2 = 256 * 32 + 32;
 constexpr int C2DW_IMG = C2_PW * C2_PW * C1;     // 9216 floats
 constexpr int C2DW_DN = 128 * C2;                // 4096 floats
 
-__global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
-                                                          float* __restrict__ part, int B) {
+__device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, const float* __restrict__ dn2,
+                                                          float* __restrict__ part, int B, int bx, int by, int gx) {
   __shared__ __attribute__((aligned(16))) float lds[C2DW_IMG + C2DW_DN];
   float* img = lds;
   float* dnl = lds + C2DW_IMG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int mt = blockIdx.y * 4 + wv, u = mt >> 2, v = mt & 3;
+  const int mt = by * 4 + wv, u = mt >> 2, v = mt & 3;
   f32x4 acc0 = zero4(), acc1 = zero4();
   float bs0 = 0.f, bs1 = 0.f;
   f32x4 simg[9], sdn[4];
@@ -681,16 +681,16 @@ __global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restric
       sdn[i] = idx < FLAT / 4 ? ld4(db + 4 * idx) : zero4();
     }
   };
-  int b = blockIdx.x;
+  int b = bx;
   if (b < B) fetch(b);
-  for (; b < B; b += gridDim.x) {
+  for (; b < B; b += gx) {
     __syncthreads();                                   // everyone is done reading the previous sample
 #pragma unroll
     for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(&img[(threadIdx.x + 256 * i) * 4]) = simg[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&dnl[(threadIdx.x + 256 * i) * 4]) = sdn[i];
     __syncthreads();
-    if (b + (int)gridDim.x < B) fetch(b + gridDim.x);
+    if (b + gx < B) fetch(b + gx);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restric
       }
     }
   }
-  float* out = part + (size_t)blockIdx.x * SLAB2;
+  float* out = part + (size_t)bx * SLAB2;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     out[(mt * 16 + 4 * g + q) * C2 + r] = acc0[q];
@@ -729,11 +729,12 @@ __global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restric
 // Pixels are grouped by parity class (py,px) so that a 16-pixel tile shares one weight sub-matrix.
 template <int PY, int PX>
 __device__ __forceinline__ void conv2_dx_class(const float* __restrict__ dn2, const float* __restrict__ w,
-                                               const float* __restrict__ n1, float* __restrict__ dn1, int B) {
+                                               const float* __restrict__ n1, float* __restrict__ dn1, int B,
+                                               int bx, int gx) {
   constexpr int NY = PY ? 10 : 11, NX = PX ? 10 : 11, CNT = NY * NX;
   constexpr int PU = 1 - PY, PV = 1 - PX;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const int wave = bx * 4 + (threadIdx.x >> 6), nwaves = gx * 4;
   const int Mc = B * CNT, ntiles = (Mc + 15) >> 4;
   float wr[32];
 #pragma unroll
@@ -777,14 +778,54 @@ __device__ __forceinline__ void conv2_dx_class(const float* __restrict__ dn2, co
   }
 }
 
+__device__ __forceinline__ void conv2_dx_body(const float* __restrict__ dn2, const float* __restrict__ w,
+                                                       const float* __restrict__ n1, float* __restrict__ dn1, int B, int bx, int by, int gx) {
+  switch (by) {   // block-uniform
+    case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, B, bx, gx); break;
+    case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, B, bx, gx); break;
+    case 2: conv2_dx_class<1, 0>(dn2, w, n1, dn1, B, bx, gx); break;
+    default: conv2_dx_class<1, 1>(dn2, w, n1, dn1, B, bx, gx); break;
+  }
+}
+
+
+// ---- launchable forms.  The two gradients of a layer (weights / inputs) only share inputs, so they are also
+// offered as ONE launch whose block range is split between the two bodies: they then run side by side and
+// fill the chip, which neither does alone at small batch (cross-stream events cost more than they save here).
+__global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict__ flat, const float* __restrict__ dd1,
+                                                        float* __restrict__ g_wd, float* __restrict__ g_bd, int B,
+                                                        HeadBwdArgs hb) {
+  dense1_dw_body(flat, dd1, g_wd, g_bd, B, hb, blockIdx.x, blockIdx.y, gridDim.x);
+}
+__global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict__ dd1, const float* __restrict__ wd,
+                                                        const float* __restrict__ n2, float* __restrict__ dn2, int B) {
+  dense1_dx_body(dd1, wd, n2, dn2, B, blockIdx.x, blockIdx.y, gridDim.x);
+}
+struct Dense1BwdArgs {
+  const float* n2; const float* dd1; const float* wd; float* g_wd; float* g_bd; float* dn2; int B;
+  HeadBwdArgs hb; int dw_gx; int dw_blocks; int dx_gx;
+};
+__global__ __launch_bounds__(256) void dense1_bwd_kernel(Dense1BwdArgs a) {
+  const int id = blockIdx.x;
+  if (id < a.dw_blocks) dense1_dw_body(a.n2, a.dd1, a.g_wd, a.g_bd, a.B, a.hb, id % a.dw_gx, id / a.dw_gx, a.dw_gx);
+  else { const int j = id - a.dw_blocks; dense1_dx_body(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx); }
+}
+__global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
+                                                          float* __restrict__ part, int B) {
+  conv2_dw_body(n1, dn2, part, B, blockIdx.x, blockIdx.y, gridDim.x);
+}
 __global__ __launch_bounds__(256) void conv2_dx_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
                                                        const float* __restrict__ n1, float* __restrict__ dn1, int B) {
-  switch (blockIdx.y) {   // block-uniform
-    case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, B); break;
-    case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, B); break;
-    case 2: conv2_dx_class<1, 0>(dn2, w, n1, dn1, B); break;
-    default: conv2_dx_class<1, 1>(dn2, w, n1, dn1, B); break;
-  }
+  conv2_dx_body(dn2, w, n1, dn1, B, blockIdx.x, blockIdx.y, gridDim.x);
+}
+struct Conv2BwdArgs {
+  const float* n1; const float* dn2; const float* w2; float* slab2; float* dn1; int B;
+  int dw_gx; int dw_blocks; int dx_gx;
+};
+__global__ __launch_bounds__(256, 2) void conv2_bwd_kernel(Conv2BwdArgs a) {
+  const int id = blockIdx.x;
+  if (id < a.dw_blocks) conv2_dw_body(a.n1, a.dn2, a.slab2, a.B, id % a.dw_gx, id / a.dw_gx, a.dw_gx);
+  else { const int j = id - a.dw_blocks; conv2_dx_body(a.dn2, a.w2, a.n1, a.dn1, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx); }
 }
 
 // ------------------------------------------------------------------ conv1 backward: dW1 partials

@@ -11,6 +11,12 @@ using namespace ga3c;
 
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1);} } while (0)
 
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int n, float seed) {
+  f32x4 a0 = zero4(), a1 = zero4();
+  float x = seed + threadIdx.x * 1e-3f, y = seed * 0.5f;
+  for (int i = 0; i < n; i += 2) { a0 = mfma(x, y, a0); a1 = mfma(y, x, a1); }
+  if (a0[0] + a1[1] == 12345.f) out[threadIdx.x] = a0[0];
+}
 __global__ void empty_kernel(float* p) { if (threadIdx.x == 9999) p[0] = 1.f; }
 
 template <typename F>
@@ -38,6 +44,11 @@ int main(int argc, char** argv) {
   std::vector<float> hw(2 << 20);
   for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 40503u) & 1023) / 8192.f - 0.06f;
   CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+  for (int n : {128, 512, 2048, 8192, 32768}) {
+    float us = time_us([&](hipEvent_t a, hipEvent_t b) {
+      hipExtLaunchKernelGGL(mfma_loop, dim3(256), dim3(256), 0, st, a, b, 0, n1, n, 0.37f); }, st, 10);
+    printf("mfma_loop 1 wave/SIMD n=%6d: %.2f us (%.1f cycles@2.4GHz per MFMA incl. floor)\n", n, us, us * 2400.0 / n);
+  }
   auto chain = [&](const char* name, auto launch, int n) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i) launch();
