@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--actions", type=int, default=6)
     ap.add_argument("--predictors", type=int, default=2, help="prediction lanes the K predict steps are dealt to (Config.PREDICTORS)")
+    ap.add_argument("--no-lane-sweep", action="store_true",
+                    help="skip the extra 1- and 3-lane legs (use with --predictors 1 under rocprofv3 so that kernels never overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length; 0 disables it")
     ap.add_argument("--e2e-seconds", type=float, default=8.0,
                     help="also run the whole engine (agent processes -> transport -> predictor/trainer threads) this long; 0 disables")
@@ -120,7 +122,7 @@ def main():
         nat.check(lib.ga3c_net_time_predict_lanes(h, B, W, NP, nat.C.byref(ev_ms)), "warmup")
     pred_s, _ = timed(0, K, lanes=NP)
     one_s, pred_ev_ms = timed(0, K)
-    three_s, _ = timed(0, K, lanes=3)
+    three_s = pred_s if args.no_lane_sweep else timed(0, K, lanes=3)[0]
     train_s, train_ev_ms = timed(1, K)
 
     out = None
