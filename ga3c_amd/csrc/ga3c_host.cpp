@@ -6,6 +6,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <linux/futex.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
@@ -128,6 +129,24 @@ bool ring_try_pop(char* base, Ring* r, uint32_t* v) {
   }
 }
 
+// The rings are sized so that they can never be logically full (one request per agent, one entry per rollout
+// slot).  ring_push can still report "full" for a moment: a consumer that has claimed a cell (CAS on deq) but
+// was descheduled before republishing the cell's sequence number blocks that one cell, and the producers come
+// round to it again after `capacity` further pushes.  That is a wait for a peer thread, not an error: yield,
+// then sleep, and only give up after ~5 s (found by the sanitizer stress test under CPU oversubscription).
+bool ring_push_wait(char* base, Ring* r, uint32_t v) {
+  for (int spin = 0; spin < 200000; ++spin) {
+    if (ring_push(base, r, v)) return true;
+    if (spin < 64) {
+      sched_yield();
+    } else {
+      struct timespec ts = {0, 25000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  return false;
+}
+
 uint32_t ring_size(Ring* r) {
   const uint64_t e = r->enq.load(std::memory_order_acquire), d = r->deq.load(std::memory_order_acquire);
   return e > d ? (uint32_t)(e - d) : 0;
@@ -245,7 +264,8 @@ int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out
       cfg->state_bytes < 16 || cfg->state_bytes % 16 != 0 || cfg->train_slots < 1 || cfg->train_slots > 65536 ||
       cfg->train_rows < 1)
     return fail(GA3C_H_EINVAL, "bad shm config");
-  const uint32_t req_cap = pow2_at_least((uint32_t)cfg->max_agents), tr_cap = pow2_at_least((uint32_t)cfg->train_slots);
+  // twice the logical maximum: fewer laps over a cell whose consumer is momentarily descheduled
+  const uint32_t req_cap = pow2_at_least(2u * (uint32_t)cfg->max_agents), tr_cap = pow2_at_least(2u * (uint32_t)cfg->train_slots);
   Header lay;
   memset((void*)&lay, 0, sizeof lay);
   int64_t off = round_up(sizeof(Header), 256);
@@ -390,7 +410,7 @@ int ga3c_pq_submit(ga3c_shm* shm, int32_t agent) {
     return fail(GA3C_H_EINVAL, "agent %d already has a request in flight", agent);
   m->req_seq += 1;
   std::atomic_thread_fence(std::memory_order_release);   // state bytes before the id becomes visible
-  if (!ring_push(shm->base, &h->req, (uint32_t)agent)) {
+  if (!ring_push_wait(shm->base, &h->req, (uint32_t)agent)) {
     m->req_seq -= 1;
     return fail(GA3C_H_EINVAL, "request ring full (more than max_agents requests in flight)");
   }
@@ -472,7 +492,7 @@ int ga3c_tq_commit(ga3c_shm* shm, int32_t slot, int32_t rows) {
   if (rows < 1 || rows > shm->hdr()->cfg.train_rows) return fail(GA3C_H_EINVAL, "rows %d outside [1,%d]", rows, shm->hdr()->cfg.train_rows);
   *reinterpret_cast<int32_t*>(shm->rollout(slot) + shm->hdr()->ro_rows_off) = rows;
   std::atomic_thread_fence(std::memory_order_release);
-  if (!ring_push(shm->base, &shm->hdr()->readyq, (uint32_t)slot)) return fail(GA3C_H_EINVAL, "ready ring full");
+  if (!ring_push_wait(shm->base, &shm->hdr()->readyq, (uint32_t)slot)) return fail(GA3C_H_EINVAL, "ready ring full");
   return GA3C_H_OK;
 }
 
@@ -491,7 +511,7 @@ int ga3c_tq_rows(ga3c_shm* shm, int32_t slot) {
 
 int ga3c_tq_release(ga3c_shm* shm, int32_t slot) {
   if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return fail(GA3C_H_EINVAL, "bad slot id");
-  if (!ring_push(shm->base, &shm->hdr()->freeq, (uint32_t)slot)) return fail(GA3C_H_EINVAL, "free ring full");
+  if (!ring_push_wait(shm->base, &shm->hdr()->freeq, (uint32_t)slot)) return fail(GA3C_H_EINVAL, "free ring full");
   return GA3C_H_OK;
 }
 
