@@ -111,6 +111,7 @@ struct ga3c_net {
   int64_t step = 0;
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+  bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
   void* reg_host = nullptr;            // HIP-registered host segment (the shm transport) ...
   uint8_t* reg_dev = nullptr;          // ... and the device-side address of its first byte
   int64_t reg_bytes = 0;
@@ -164,8 +165,17 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
   const float* th = net->theta[idx];
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * 7), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, B);
-  hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
+  if (net->fused_conv) {
+    if (train)
+      hipLaunchKernelGGL(conv_stack_fwd_kernel<true>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), st, f.x,
+                         th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, f.n1, f.n2, B);
+    else
+      hipLaunchKernelGGL(conv_stack_fwd_kernel<false>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), st, f.x,
+                         th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, f.n1, f.n2, B);
+  } else {
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * 7), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, B);
+    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
+  }
   const int ks = dense_ks(B);
   if (B <= 256)
     hipLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
@@ -454,6 +464,18 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   ga3c_net* net = new (std::nothrow) ga3c_net();
   if (!net) return fail(GA3C_EINVAL, "out of host memory");
   net->cfg = *cfg;
+  net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
+  if (net->fused_conv) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_fwd_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CS_LDS_FLOATS * sizeof(float)));
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_fwd_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CS_LDS_FLOATS * sizeof(float)));
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      delete net;
+      return fail(GA3C_EHIP, "cannot reserve %d bytes of LDS for conv_stack_fwd_kernel: %s", (int)(CS_LDS_FLOATS * sizeof(float)),
+                  hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    }
+  }
   net->A = cfg->num_actions;
   net->maxB = cfg->max_batch;
   net->n = arena_floats(net->A);
@@ -844,6 +866,9 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       TL(conv1_fwd_kernel, dim3(B * 7), t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, B);
     } else if (k == "conv2_fwd") {
       TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
+    } else if (k == "conv_stack_fwd") {
+      hipExtLaunchKernelGGL(conv_stack_fwd_kernel<false>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st, t.ev0,
+                            t.ev1, 0, t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B);
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
       if (B <= 256)

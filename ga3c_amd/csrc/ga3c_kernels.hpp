@@ -248,6 +248,136 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ conv1 + conv2 forward in one launch
+// Workgroup (16 waves) = (sample, upper / lower half of the conv2 output).  The x rows the half needs (56 or
+// 44 padded rows, <= 77 KB) and both filter banks go to LDS once; conv1 runs tile by tile and leaves its
+// ReLU output in an LDS image of n1 laid out for conv2 (zero border included), conv2 then reads its patches
+// from that image.  n1 never travels to HBM in prediction (TRAIN also stores it: the backward pass needs it).
+// Rows 11,12 of n1 are needed by both halves and are computed twice (+9.5% conv1 MFMAs, identical values).
+// Saves one launch and the 3.6 MB write + 7.2 MB read of n1 per 128 states against conv1_fwd + conv2_fwd.
+constexpr int CS_XROWS = 56;                                  // upper half; lower half uses 44
+constexpr int CS_X_FLOATS = CS_XROWS * C1_PW * 4;             // 19712
+constexpr int CS_N1ROWS = 14;                                 // upper: n1 rows -1..12; lower: 11..22 (12 used)
+constexpr int CS_N1_FLOATS = CS_N1ROWS * C2_PW * C1;          // 5376
+constexpr int CS_LDS_FLOATS = CS_X_FLOATS + CS_N1_FLOATS + 64 * 64 + 2 * 64 * 64;   // 37376 floats = 149,504 B
+
+template <bool TRAIN>
+__global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, float* __restrict__ n1,
+                                                             float* __restrict__ n2, int B) {
+  extern __shared__ __attribute__((aligned(16))) float cs_lds[];
+  float* img = cs_lds;
+  float* n1l = cs_lds + CS_X_FLOATS;
+  float* wl1 = n1l + CS_N1_FLOATS;
+  float* wl2 = wl1 + 64 * 64;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x >> 1, h = blockIdx.x & 1;
+  const int c2r0 = h ? 6 : 0, c2nr = h ? 5 : 6;              // conv2 output rows of this half
+  const int n1r0 = h ? 11 : 0, n1nr = h ? 10 : 13;           // n1 rows it needs
+  const int n1org = 2 * c2r0 - 1;                            // n1 row held by LDS image row 0
+  const int xr0 = 4 * n1r0 - 2, xnr = 4 * n1nr + 4;          // x rows it needs (56 / 44)
+  const float* xb = x + (size_t)b * XS;
+  // ---- stage x rows (zero padded), W1, W2; clear the n1 image.  All global loads are issued before the
+  // first LDS store, so the block pays one memory round trip.
+  const int npx = xnr * C1_PW;                               // <= 4928 pixels -> at most 5 per thread
+  f32x4 sx[5], sw1, sw2[2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int idx = threadIdx.x + 1024 * i;
+    const int row = idx / C1_PW, col = idx - row * C1_PW;
+    const int yy = xr0 + row, xx = col - 2;
+    const bool ok = idx < npx && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+    sx[i] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
+  }
+  sw1 = ld4(w1 + 4 * threadIdx.x);                           // W1[256][16] = 1024 float4
+  sw2[0] = ld4(w2 + 4 * threadIdx.x);                        // W2[256][32] = 2048 float4
+  sw2[1] = ld4(w2 + 4 * (threadIdx.x + 1024));
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int idx = threadIdx.x + 1024 * i;
+    if (idx < npx) *reinterpret_cast<f32x4*>(&img[idx * 4]) = sx[i];
+  }
+  {
+    const int idx4 = threadIdx.x, k = idx4 >> 2, n = (idx4 & 3) * 4;
+    *reinterpret_cast<f32x4*>(&wl1[((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + n]) = sw1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx4 = threadIdx.x + 1024 * i, k = idx4 >> 3, n4 = (idx4 & 7) * 4;
+    *reinterpret_cast<f32x4*>(&wl2[(n4 >> 4) * 4096 + ((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + (n4 & 15)]) = sw2[i];
+  }
+  for (int idx4 = threadIdx.x; idx4 < CS_N1_FLOATS / 4; idx4 += 1024) *reinterpret_cast<f32x4*>(&n1l[idx4 * 4]) = zero4();
+  __syncthreads();
+  // ---- conv1 over the half's n1 pixels, result into the LDS image (and to HBM when training)
+  {
+    float wr[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wr[j] = wl1[j * 64 + lane];
+    const float bv = b1[r];
+    const int npix = n1nr * O1, ntile = (npix + 15) >> 4;
+    for (int tile = wv; tile < ntile; tile += 16) {
+      const int ml = tile * 16 + r;
+      const int mm = ml < npix ? ml : 0;
+      const int il = mm / O1, j = mm - il * O1;
+      const float* base = img + ((4 * il) * C1_PW + 4 * j + g) * 4;
+      f32x4 a[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 1) * C1_PW + (s & 1) * 4) * 4);
+      f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc0 = mfma(a[s][t], wr[s * 4 + t], acc0);
+          acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mr = tile * 16 + 4 * g + q;
+        if (mr < npix) {
+          const int ir = mr / O1, jr = mr - ir * O1;
+          const float val = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
+          n1l[((n1r0 + ir - n1org) * C2_PW + jr + 1) * C1 + r] = val;
+          if (TRAIN) n1[((size_t)b * P1 + (n1r0 + ir) * O1 + jr) * C1 + r] = val;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- conv2 from the LDS image: items = (16-pixel tile, 16-column half)
+  {
+    const int npix = c2nr * O2, nitem = 2 * ((npix + 15) >> 4);
+    for (int item = wv; item < nitem; item += 16) {
+      const int tile = item >> 1, hh = item & 1;
+      const float* wf = wl2 + hh * 4096;
+      const int ml = tile * 16 + r;
+      const int mm = ml < npix ? ml : 0;
+      const int i2 = mm / O2, j2 = mm - i2 * O2;
+      const float* base = n1l + ((2 * i2) * C2_PW + 2 * j2) * C1 + 4 * g;
+      f32x4 a[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 2) * C2_PW + (s & 3)) * C1);
+      f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc0 = mfma(a[s][t], wf[(s * 4 + t) * 64 + lane], acc0);
+          acc1 = mfma(a[s + 1][t], wf[((s + 1) * 4 + t) * 64 + lane], acc1);
+        }
+      }
+      const float bv = b2[hh * 16 + r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mr = tile * 16 + 4 * g + q;
+        if (mr < npix) n2[(size_t)b * FLAT + ((size_t)c2r0 * O2 + mr) * C2 + hh * 16 + r] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ dense1 weight packing
 // pk[(s*256 + n)*16 + kk] = Wd[16 s + kk][n]: the B-operand fragment order of dense1_fwd, so that a lane's
 // four k values of a step are one 16-byte load and a wave instruction reads 1 KB contiguously.
