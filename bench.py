@@ -26,6 +26,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this stack
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
@@ -33,6 +35,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 FLOP_PER_PREDICTION = {4: 7_580_160, 6: 7_581_184, 18: 7_587_328}
 FLOP_CONV1_PER_SAMPLE = 3_612_672                                       # 441 * 256 * 16 * 2
+FLOP_CONV2_PER_SAMPLE = 1_982_464                                       # 121 * 256 * 32 * 2
 MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
 
 
@@ -156,17 +159,19 @@ def main():
             nat.check(lib.ga3c_net_time_kernel(h, name.encode(), B, 5, nat.C.byref(ev_ms)), name)
             nat.check(lib.ga3c_net_time_kernel(h, name.encode(), B, iters, nat.C.byref(ev_ms)), name)
             kernels[name] = ev_ms.value / iters * 1e3          # microseconds per launch
-        t_conv1 = kernels["conv1_fwd"] * 1e-6
-        achieved = FLOP_CONV1_PER_SAMPLE * B / t_conv1 / 1e12
+        # dominant kernel of the prediction step: the fused conv stack (conv1 + conv2 = 74 % of the forward FLOPs)
+        flop_launch = (FLOP_CONV1_PER_SAMPLE + FLOP_CONV2_PER_SAMPLE) * B
+        t_conv = kernels["conv_stack_fwd"] * 1e-6
+        achieved = flop_launch / t_conv / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("conv1_fwd_B%d" % B)
-        out["roofline"] = {"kernel": "conv1_fwd_kernel", "bound": "mfma", "achieved": achieved,
+                traffic = json.load(f).get("conv_stack_fwd_B%d" % B)
+        out["roofline"] = {"kernel": "conv_stack_fwd_kernel<false>", "bound": "mfma", "achieved": achieved,
                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                           "traffic": traffic, "avg_launch_us": kernels["conv1_fwd"],
-                           "algorithmic_flop_per_launch": FLOP_CONV1_PER_SAMPLE * B}
+                           "traffic": traffic, "avg_launch_us": kernels["conv_stack_fwd"],
+                           "algorithmic_flop_per_launch": flop_launch}
         out["kernel_us"] = kernels
         flop = FLOP_PER_PREDICTION.get(A, 7_581_184)
         out["end_to_end_mfma_frac"] = out["value"] * flop / (world * MFMA_F32_PEAK_TFLOPS * 1e12)
