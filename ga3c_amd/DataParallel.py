@@ -41,3 +41,48 @@ def attach(net, rank, world):
     if world > 1:
         net.comm_init(exchange_comm_id(type(net).make_comm_id, rank), rank, world)
     return net
+
+
+class EngineGroup:
+    """Lock-step control plane for one Server per GPU (launched with torch.distributed.run).
+
+    Every train step contains an RCCL all-reduce, so all ranks must take exactly the same number of steps.
+    Rank 0 decides when to stop; the decision travels as "stop after global step S" over the gloo group, polled
+    by every rank's main loop (Server.main, 100 Hz).  Trainer threads take a step only while the model's
+    global step is below S, checked under Server.dp_lock, so all ranks end on the same step and none is left
+    waiting inside a collective.
+    """
+    MARGIN = 32      # steps between the decision and the stop, so that every rank hears of it in time
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.stop_step = None
+
+    @classmethod
+    def from_env(cls):
+        import torch.distributed as dist
+        rank, local_rank, world = env_rank_world()
+        if world <= 1:
+            return None
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return cls(rank, world)
+
+    def poll(self, want_stop, current_step, lr, beta):
+        """Collective: call once per main-loop turn on every rank.
+        Returns (agreed stop step or None, learning rate, beta) -- the last two are rank 0's, so that every rank
+        applies the same optimizer step (the anneal of Server.py:168-175 follows rank 0's episode count)."""
+        import torch
+        import torch.distributed as dist
+        msg = torch.zeros(4, dtype=torch.float64)
+        if self.rank == 0:
+            if self.stop_step is None and want_stop:
+                self.stop_step = int(current_step) + self.MARGIN
+            msg[0] = 1.0 if self.stop_step is not None else 0.0
+            msg[1] = float(self.stop_step or 0)
+            msg[2], msg[3] = float(lr), float(beta)
+        dist.broadcast(msg, src=0, group=self.group)
+        if msg[0] == 1.0:
+            self.stop_step = int(msg[1])
+        return self.stop_step, float(msg[2]), float(msg[3])

@@ -24,5 +24,13 @@ def apply_argv(argv):
 
 if __name__ == '__main__':
     apply_argv(sys.argv[1:])
+    import DataParallel
+    group = DataParallel.EngineGroup.from_env()          # None unless launched with WORLD_SIZE > 1
+    if group is not None:
+        _, local_rank, _ = DataParallel.env_rank_world()
+        Config.DEVICE = 'gpu:%d' % local_rank
+        Config.RANDOM_SEED += 100003 * group.rank        # different synthetic episodes on every rank
+        Config.RESULTS_FILENAME = 'results_rank%d.txt' % group.rank
+        Config.SAVE_MODELS = Config.SAVE_MODELS and group.rank == 0
     from Server import Server
-    Server().main()
+    Server(engine_group=group).main()

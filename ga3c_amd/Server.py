@@ -8,9 +8,11 @@ What changed against the reference, and why:
     TensorFlow class (Server.py:48-54);
   * agents are started from a forkserver, so they never inherit the server's HIP state.
 """
+import threading
 import time
 
 from Config import Config
+import DataParallel
 from Environment import Environment
 from NetworkVP import Network
 from ProcessAgent import ProcessAgent, config_snapshot
@@ -22,7 +24,12 @@ import Transport as tp
 
 
 class Server:
-    def __init__(self, model=None, max_agents=None):
+    def __init__(self, model=None, max_agents=None, engine_group=None):
+        # one Server per GPU under torch.distributed.run: lock-step training over RCCL (DataParallel.py)
+        self.dp = engine_group
+        self.dp_lock = threading.Lock()
+        self.dp_started = False
+        self.stop_step = None
         self.stats = ProcessStats()
         self.state_dim = self.get_state_dim()
         self.num_actions = self.get_num_action()
@@ -33,6 +40,8 @@ class Server:
                                              Config.MAX_QUEUE_SIZE, Config.TIME_MAX + 1)
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
                                                              self.state_dim)
+        if self.dp is not None and hasattr(self.model, "comm_init"):
+            DataParallel.attach(self.model, self.dp.rank, self.dp.world)
         # let the GPU read states straight out of the transport's slots (no host gather, no staging copy)
         self.zero_copy = bool(Config.ZERO_COPY) and hasattr(self.model, "register_transport")
         if self.zero_copy:
@@ -86,9 +95,19 @@ class Server:
         self.trainers.pop()
 
     # ---- training bookkeeping (Server.py:141-153) ----------------------------------------------
+    def _may_step(self):
+        """Data-parallel runs start after the first poll (shared lr / beta) and stop on an agreed global step
+        (EngineGroup); single-GPU runs never refuse."""
+        if self.dp is not None and not self.dp_started:
+            return False
+        return self.stop_step is None or self.training_step < self.stop_step
+
     def train_model(self, x_, r_, a_, x2, done, trainer_id):
-        self.model.train(x_, r_, a_, x2, done, trainer_id)
-        self._count_train_step(x_.shape[0], x_, r_, a_)
+        with self.dp_lock:
+            if not self._may_step():
+                return
+            self.model.train(x_, r_, a_, x2, done, trainer_id)
+            self._count_train_step(x_.shape[0], x_, r_, a_)
 
     def _count_train_step(self, rows, x_, r_, a_):
         self.training_step += 1
@@ -100,8 +119,11 @@ class Server:
 
     def train_model_rows(self, row_offsets, r_, a_, trainer_id):
         """train_model for rows that are still sitting in the transport (zero-copy intake)."""
-        self.model.train_offsets(row_offsets, r_, a_)
-        self._count_train_step(row_offsets.shape[0], None, r_, a_)
+        with self.dp_lock:
+            if not self._may_step():
+                return
+            self.model.train_offsets(row_offsets, r_, a_)
+            self._count_train_step(row_offsets.shape[0], None, r_, a_)
 
     def save_model(self):
         self.model.save(self.stats.episode_count.value)
@@ -114,14 +136,23 @@ class Server:
         beta_mult = (Config.BETA_END - Config.BETA_START) / Config.ANNEALING_EPISODE_COUNT
         t0 = time.time()
         try:
-            while self.stats.episode_count.value < Config.EPISODES:
+            while self.dp is not None or self.stats.episode_count.value < Config.EPISODES:
                 step = min(self.stats.episode_count.value, Config.ANNEALING_EPISODE_COUNT - 1)
-                self.model.learning_rate = Config.LEARNING_RATE_START + lr_mult * step
-                self.model.beta = Config.BETA_START + beta_mult * step
+                lr = Config.LEARNING_RATE_START + lr_mult * step
+                beta = Config.BETA_START + beta_mult * step
                 if Config.SAVE_MODELS and self.stats.should_save_model.value > 0:
                     self.save_model()
                     self.stats.should_save_model.value = 0
-                if max_seconds is not None and time.time() - t0 > max_seconds:
+                timed_out = max_seconds is not None and time.time() - t0 > max_seconds
+                if self.dp is not None:   # all ranks leave on the step rank 0 announces, and use rank 0's lr / beta
+                    want_stop = timed_out or self.stats.episode_count.value >= Config.EPISODES
+                    self.stop_step, lr, beta = self.dp.poll(want_stop, self.training_step, lr, beta)
+                self.model.learning_rate, self.model.beta = lr, beta
+                self.dp_started = True
+                if self.dp is None:
+                    if timed_out:
+                        break
+                elif self.stop_step is not None and self.training_step >= self.stop_step:
                     break
                 time.sleep(0.01)
         finally:
