@@ -165,7 +165,7 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
   const float* th = net->theta[idx];
-  if (net->fused_conv) {
+  if (net->fused_conv && B <= 160) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
     if (train)
       hipLaunchKernelGGL(conv_stack_fwd_kernel<true>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), st, f.x,
                          th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, f.n1, f.n2, B);
@@ -212,18 +212,14 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
     Dense1BwdArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
     d.hb = hb; d.dw_gx = FLAT / 32 + A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
-    const int dx_blocks = d.dx_gx * (((B + 15) / 16 + 3) / 4);
+    d.dx_mt = B > 192 ? 4 : 1;
+    const int dx_blocks = d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4);
     hipLaunchKernelGGL(dense1_bwd_kernel, dim3(d.dw_blocks + dx_blocks), dim3(256), 0, st, d);
   }
   const int nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
-  {
-    Conv2BwdArgs c;
-    c.n1 = t.f.n1; c.dn2 = t.dn2; c.w2 = th + OFF_W2; c.slab2 = t.slab2; c.dn1 = t.dn1; c.B = B;
-    c.dw_gx = nch2; c.dw_blocks = 4 * nch2;
-    const int nt = (B * P2 + 15) / 16;
-    c.dx_gx = (nt + 3) / 4 > 256 ? 256 : (nt + 3) / 4;
-    hipLaunchKernelGGL(conv2_bwd_kernel, dim3(c.dw_blocks + 4 * c.dx_gx), dim3(256), 0, st, c);
-  }
+  // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
+  hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+  hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
   const int nch1 = B * 7 < 512 ? B * 7 : 512;  // workgroups = partial slabs
   hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch1), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, B * 7);
   {
@@ -882,10 +878,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "conv2_dw") {
       TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
-      const int nt = (B * P2 + 15) / 16;
-      int blocks = (nt + 3) / 4;
-      if (blocks > 256) blocks = 256;
-      TL(conv2_dx_kernel, dim3(blocks, 4), t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+      TL(conv2_dx_kernel, dim3(B, 4), t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
     } else if (k == "dense1_dw") {
       HeadBwdArgs hb;
       hb.B = B; hb.A = net->A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
@@ -899,13 +892,13 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.hb.B = B; d.hb.A = net->A; d.hb.d1 = t.f.d1; d.hb.dz = t.dz; d.hb.dv = t.dv; d.hb.lossrow = t.lossrow;
       d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
       d.dw_gx = FLAT / 32 + net->A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
-      TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 15) / 16 + 3) / 4)), d);
+      d.dx_mt = B > 192 ? 4 : 1;
+      TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4)), d);
     } else if (k == "conv2_bwd") {
       Conv2BwdArgs c;
       c.n1 = t.f.n1; c.dn2 = t.dn2; c.w2 = th + OFF_W2; c.slab2 = t.slab2; c.dn1 = t.dn1; c.B = B;
       c.dw_gx = B < 256 ? B : 256; c.dw_blocks = 4 * c.dw_gx;
-      const int nt = (B * P2 + 15) / 16;
-      c.dx_gx = (nt + 3) / 4 > 256 ? 256 : (nt + 3) / 4;
+      c.dx_gx = B;
       TL(conv2_bwd_kernel, dim3(c.dw_blocks + 4 * c.dx_gx), c);
     } else if (k == "heads") {
       HeadArgs h;

@@ -724,51 +724,61 @@ __device__ __forceinline__ void dense1_dw_body(const float* __restrict__ flat, c
 }
 
 // ------------------------------------------------------------------ dense1 backward: dn2 = (dd1 Wd^T) * 1[n2>0]
-// M = B, N = 3872, K = 256.  Both operands are k-contiguous (16-byte loads).  Wave tile 16 x 32.
-// grid.x = 121 column blocks of 32... each block's 4 waves take 4 consecutive m-tiles; grid.y covers the rest.
+// M = B, N = 3872, K = 256.  Both operands are k-contiguous (16-byte loads).  Wave tile (16*MT) x 32: the two Wd
+// row fragments a wave loads are reused for MT row tiles (MT = 1 at small batch for parallelism, 4 at large batch
+// where re-reading Wd once per 16 rows was the bottleneck).  bx = column block of 32, by*4 + wave = row block.
+template <int MT>
 __device__ __forceinline__ void dense1_dx_body(const float* __restrict__ dd1, const float* __restrict__ wd,
-                                                        const float* __restrict__ n2, float* __restrict__ dn2, int B, int bx, int by, int gx) {
+                                               const float* __restrict__ n2, float* __restrict__ dn2, int B, int bx, int by,
+                                               int gx) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int n0 = bx * 32;
-  const int m0 = (by * 4 + (threadIdx.x >> 6)) * 16;
+  const int m0 = (by * 4 + (threadIdx.x >> 6)) * 16 * MT;
   if (m0 >= B) return;   // wave-uniform
-  const int row = m0 + r;
-  const bool valid = row < B;
-  const float* arow = dd1 + (size_t)(valid ? row : 0) * HID + 4 * g;
   const float* b0 = wd + (size_t)(n0 + r) * HID + 4 * g;
   const float* b1 = wd + (size_t)(n0 + 16 + r) * HID + 4 * g;
-  // K = 256 only: all 48 operand loads (and the ReLU mask) are issued before the first MFMA
-  f32x4 a[16], w0[16], w1[16];
+  // K = 256 only: the Wd fragments (32 x 16-byte loads) are issued up front and stay in registers
+  f32x4 w0[16], w1[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    a[s] = valid ? ld4(arow + 16 * s) : zero4();
     w0[s] = ld4(b0 + 16 * s);
     w1[s] = ld4(b1 + 16 * s);
   }
-  float mask0[4], mask1[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int mr = m0 + 4 * g + q;
-    const size_t o = (size_t)(mr < B ? mr : 0) * FLAT + n0 + r;
-    mask0[q] = n2[o];
-    mask1[q] = n2[o + 16];
-  }
-  f32x4 acc0 = zero4(), acc1 = zero4();
+  for (int mi = 0; mi < MT; ++mi) {
+    const int mbase = m0 + 16 * mi;
+    if (mbase >= B) break;   // wave-uniform
+    const int row = mbase + r;
+    const bool valid = row < B;
+    const float* arow = dd1 + (size_t)(valid ? row : 0) * HID + 4 * g;
+    f32x4 a[16];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 16; ++s) a[s] = valid ? ld4(arow + 16 * s) : zero4();
+    float mask0[4], mask1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc0 = mfma(a[s][t], w0[s][t], acc0);
-      acc1 = mfma(a[s][t], w1[s][t], acc1);
+    for (int q = 0; q < 4; ++q) {
+      const int mr = mbase + 4 * g + q;
+      const size_t o = (size_t)(mr < B ? mr : 0) * FLAT + n0 + r;
+      mask0[q] = n2[o];
+      mask1[q] = n2[o + 16];
     }
-  }
+    f32x4 acc0 = zero4(), acc1 = zero4();
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int mr = m0 + 4 * g + q;
-    if (mr < B) {
-      const size_t o = (size_t)mr * FLAT + n0 + r;
-      dn2[o] = mask0[q] > 0.f ? acc0[q] : 0.f;
-      dn2[o + 16] = mask1[q] > 0.f ? acc1[q] : 0.f;
+    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma(a[s][t], w0[s][t], acc0);
+        acc1 = mfma(a[s][t], w1[s][t], acc1);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = mbase + 4 * g + q;
+      if (mr < B) {
+        const size_t o = (size_t)mr * FLAT + n0 + r;
+        dn2[o] = mask0[q] > 0.f ? acc0[q] : 0.f;
+        dn2[o + 16] = mask1[q] > 0.f ? acc1[q] : 0.f;
+      }
     }
   }
 }
@@ -857,67 +867,95 @@ __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, cons
 // dn1[b,y,x,c] = 1[n1>0] sum_{ua,va in {0,1}} sum_o dn2[b,i,j,o] W2[u,v,c,o],
 //   i = ((y+1)>>1) - ua, u = ((y+1)&1) + 2 ua (same for x): K = 4 taps * 32 = 128, N = 16.
 // Pixels are grouped by parity class (py,px) so that a 16-pixel tile shares one weight sub-matrix.
+// Workgroup = (sample, class): the sample's dn2 goes to LDS once with a zero row/column for i = -1 / j = -1,
+// the class's 128 x 16 weight sub-matrix goes to LDS in fragment order, and the 7-8 tiles of the class are
+// dealt to the 4 waves.  No atomics, no col buffer; every dn1 element is written exactly once.
+constexpr int C2DX_DN = 12 * 12 * C2;       // padded dn2 image: (i+1, j+1), 4608 floats
+constexpr int C2DX_W = 32 * 64;             // weight fragments of one class
+
 template <int PY, int PX>
 __device__ __forceinline__ void conv2_dx_class(const float* __restrict__ dn2, const float* __restrict__ w,
-                                               const float* __restrict__ n1, float* __restrict__ dn1, int B,
-                                               int bx, int gx) {
+                                               const float* __restrict__ n1, float* __restrict__ dn1, int b,
+                                               float* __restrict__ dnl, float* __restrict__ wl) {
   constexpr int NY = PY ? 10 : 11, NX = PX ? 10 : 11, CNT = NY * NX;
   constexpr int PU = 1 - PY, PV = 1 - PX;
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int wave = bx * 4 + (threadIdx.x >> 6), nwaves = gx * 4;
-  const int Mc = B * CNT, ntiles = (Mc + 15) >> 4;
-  float wr[32];
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  // ---- stage: padded dn2 image (1152 float4) and the class's weight fragments (2048 floats)
+  const float* db = dn2 + (size_t)b * FLAT;
+  f32x4 sd[5];
+  float sw[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int ua = s >> 2, va = (s >> 1) & 1, half = s & 1;
-    const int u = PU + 2 * ua, v = PV + 2 * va;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wr[s * 4 + t] = w[((u * 4 + v) * 16 + r) * C2 + half * 16 + 4 * g + t];
+  for (int i = 0; i < 5; ++i) {
+    const int idx = threadIdx.x + 256 * i;                 // float4 index into [12][12][8]
+    const int pi = idx >> 3, pr = pi / 12, pc = pi - pr * 12;
+    const bool ok = idx < C2DX_DN / 4 && pr >= 1 && pc >= 1;
+    sd[i] = ok ? ld4(db + ((pr - 1) * O2 + (pc - 1)) * C2 + (idx & 7) * 4) : zero4();
   }
-  for (int tile = wave; tile < ntiles; tile += nwaves) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = threadIdx.x + 256 * k;                   // (j = s*4+t, lane)
+    const int j = e >> 6, ln = e & 63, s = j >> 2, t = j & 3;
+    const int u = PU + 2 * (s >> 2), v = PV + 2 * ((s >> 1) & 1);
+    sw[k] = w[((u * 4 + v) * 16 + (ln & 15)) * C2 + (s & 1) * 16 + 4 * (ln >> 4) + t];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    if (idx < C2DX_DN / 4) *reinterpret_cast<f32x4*>(&dnl[idx * 4]) = sd[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) wl[threadIdx.x + 256 * k] = sw[k];
+  __syncthreads();
+  constexpr int NTILE = (CNT + 15) / 16;
+  const float* n1b = n1 + (size_t)b * N1S;
+  float* d1b = dn1 + (size_t)b * N1S;
+  for (int tile = wv; tile < NTILE; tile += 4) {
     const int mc = tile * 16 + r;
-    const bool valid = mc < Mc;
-    const int mm = valid ? mc : 0;
-    const int b = mm / CNT, rem = mm - b * CNT, ya = rem / NX, xa = rem - ya * NX;
+    const int mm = mc < CNT ? mc : 0;
+    const int ya = mm / NX, xa = mm - ya * NX;
     const int ih = (2 * ya + PY + 1) >> 1, jh = (2 * xa + PX + 1) >> 1;
-    const float* db = dn2 + (size_t)b * FLAT + 4 * g;
+    // ReLU mask of the 4 pixels this lane will write
+    float mask[4];
+    int off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = tile * 16 + 4 * g + q;
+      const int m2 = mr < CNT ? mr : 0;
+      const int ya2 = m2 / NX, xa2 = m2 - ya2 * NX;
+      off[q] = ((2 * ya2 + PY) * O1 + (2 * xa2 + PX)) * C1 + r;
+      mask[q] = n1b[off[q]];
+    }
     f32x4 a[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int i = ih - (s >> 2), j = jh - ((s >> 1) & 1);
-      const bool ok = valid && (unsigned)i < (unsigned)O2 && (unsigned)j < (unsigned)O2;
-      a[s] = ok ? ld4(db + (i * O2 + j) * C2 + (s & 1) * 16) : zero4();
-    }
+    for (int s = 0; s < 8; ++s)
+      a[s] = ld4(dnl + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
     f32x4 acc0 = zero4(), acc1 = zero4();
 #pragma unroll
     for (int s = 0; s < 8; s += 2)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc0 = mfma(a[s][t], wr[s * 4 + t], acc0);
-        acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
+        acc0 = mfma(a[s][t], wl[(s * 4 + t) * 64 + lane], acc0);
+        acc1 = mfma(a[s + 1][t], wl[((s + 1) * 4 + t) * 64 + lane], acc1);
       }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int mr = tile * 16 + 4 * g + q;
-      if (mr < Mc) {
-        const int b2 = mr / CNT, rem2 = mr - b2 * CNT, ya2 = rem2 / NX, xa2 = rem2 - ya2 * NX;
-        const size_t o = (size_t)b2 * N1S + ((2 * ya2 + PY) * O1 + (2 * xa2 + PX)) * C1 + r;
-        dn1[o] = n1[o] > 0.f ? acc0[q] + acc1[q] : 0.f;
-      }
-    }
+    for (int q = 0; q < 4; ++q)
+      if (tile * 16 + 4 * g + q < CNT) d1b[off[q]] = mask[q] > 0.f ? acc0[q] + acc1[q] : 0.f;
   }
 }
 
 __device__ __forceinline__ void conv2_dx_body(const float* __restrict__ dn2, const float* __restrict__ w,
-                                                       const float* __restrict__ n1, float* __restrict__ dn1, int B, int bx, int by, int gx) {
-  switch (by) {   // block-uniform
-    case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, B, bx, gx); break;
-    case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, B, bx, gx); break;
-    case 2: conv2_dx_class<1, 0>(dn2, w, n1, dn1, B, bx, gx); break;
-    default: conv2_dx_class<1, 1>(dn2, w, n1, dn1, B, bx, gx); break;
+                                              const float* __restrict__ n1, float* __restrict__ dn1, int B, int bx, int by,
+                                              int gx) {
+  __shared__ __attribute__((aligned(16))) float c2dx_lds[C2DX_DN + C2DX_W];
+  float* dnl = c2dx_lds;
+  float* wl = c2dx_lds + C2DX_DN;
+  switch (by) {   // block-uniform: bx = sample, by = parity class
+    case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, bx, dnl, wl); break;
+    case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, bx, dnl, wl); break;
+    case 2: conv2_dx_class<1, 0>(dn2, w, n1, dn1, bx, dnl, wl); break;
+    default: conv2_dx_class<1, 1>(dn2, w, n1, dn1, bx, dnl, wl); break;
   }
 }
-
 
 // ---- launchable forms.  The two gradients of a layer (weights / inputs) only share inputs, so they are also
 // offered as ONE launch whose block range is split between the two bodies: they then run side by side and
@@ -929,16 +967,20 @@ __global__ __launch_bounds__(256) void dense1_dw_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void dense1_dx_kernel(const float* __restrict__ dd1, const float* __restrict__ wd,
                                                         const float* __restrict__ n2, float* __restrict__ dn2, int B) {
-  dense1_dx_body(dd1, wd, n2, dn2, B, blockIdx.x, blockIdx.y, gridDim.x);
+  dense1_dx_body<1>(dd1, wd, n2, dn2, B, blockIdx.x, blockIdx.y, gridDim.x);
 }
 struct Dense1BwdArgs {
   const float* n2; const float* dd1; const float* wd; float* g_wd; float* g_bd; float* dn2; int B;
-  HeadBwdArgs hb; int dw_gx; int dw_blocks; int dx_gx;
+  HeadBwdArgs hb; int dw_gx; int dw_blocks; int dx_gx; int dx_mt;
 };
 __global__ __launch_bounds__(256) void dense1_bwd_kernel(Dense1BwdArgs a) {
   const int id = blockIdx.x;
   if (id < a.dw_blocks) dense1_dw_body(a.n2, a.dd1, a.g_wd, a.g_bd, a.B, a.hb, id % a.dw_gx, id / a.dw_gx, a.dw_gx);
-  else { const int j = id - a.dw_blocks; dense1_dx_body(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx); }
+  else {
+    const int j = id - a.dw_blocks;
+    if (a.dx_mt == 4) dense1_dx_body<4>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
+    else dense1_dx_body<1>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
+  }
 }
 __global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
                                                           float* __restrict__ part, int B) {
