@@ -107,7 +107,8 @@ def test_activations_match_oracle(nets):
         assert np.max(np.abs(got - want)) < TOL, name
 
 
-@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 5, {}), (6, 37, {}), (6, 128, {}), (4, 16, {}), (18, 21, {})])
+@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 1, {}), (6, 2, {}), (6, 5, {}), (6, 37, {}), (6, 128, {}), (6, 160, {}),
+                                                   (4, 16, {}), (18, 21, {}), (1, 9, {}), (25, 7, {}), (64, 6, {})])
 def test_gradients_match_oracle(nets, num_actions, bsz, flags):
     net = nets(num_actions)
     _, x, a, y = _batch(bsz, num_actions, 300 + bsz)
