@@ -23,6 +23,8 @@ from Experience import Experience
 import Transport as tp
 
 MP = mp.get_context("forkserver")     # children never inherit the server's HIP state
+# the fork server imports the agent's modules once; every agent then starts as a fork of that warm process
+MP.set_forkserver_preload(["numpy", "Config", "Experience", "Environment", "_native", "Transport", "ProcessAgent"])
 
 
 def config_snapshot():

@@ -59,7 +59,7 @@ def _rank_main(rank, world, port, tmp, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
+@pytest.mark.timeout(600)
 def test_two_servers_stop_on_the_same_train_step(tmp_path):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -71,9 +71,9 @@ def test_two_servers_stop_on_the_same_train_step(tmp_path):
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=150) for _ in procs)
+    res = sorted(q.get(timeout=500) for _ in procs)
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
     (r0, steps0, m0, lr0), (r1, steps1, m1, lr1) = res
     assert steps0 == steps1 == m0 == m1 and steps0 > 10

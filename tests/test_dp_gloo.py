@@ -57,7 +57,7 @@ def _worker(rank, world, port, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 def test_two_rank_sum_allreduce_equals_single_process_step():
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -66,7 +66,7 @@ def test_two_rank_sum_allreduce_equals_single_process_step():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=240) for _ in procs)
+    results = sorted(q.get(timeout=500) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
