@@ -267,3 +267,21 @@ def test_large_batch_and_u8_train_path(nets):
     net.compute_grads(x[256:], y[256:], a[256:])
     g_hi = net.get_arena(3)
     assert np.max(np.abs(g_all - (g_lo + g_hi))) < 1e-4 * max(1.0, np.max(np.abs(g_all)))
+
+
+def test_batch_row_permutation_properties(nets):
+    """Full predictor batch (128, BASELINE configs[1]): rows are independent, so permuting the batch permutes the
+    outputs bit for bit; the sum-reduced gradient is permutation invariant up to f32 summation order."""
+    net = nets(6)
+    _, x, a, y = _batch(128, 6, 404)
+    perm = np.random.default_rng(1).permutation(128)
+    p, v, z = net.predict_p_v_logits(x)
+    pp, vp, zp = net.predict_p_v_logits(x[perm])
+    assert np.array_equal(p[perm], pp) and np.array_equal(v[perm], vp) and np.array_equal(z[perm], zp)
+    net.beta = 0.01
+    l1 = net.compute_grads(x, y, a)
+    g1 = net.get_arena(3)
+    l2 = net.compute_grads(x[perm], y[perm], a[perm])
+    g2 = net.get_arena(3)
+    assert np.allclose(l1, l2, rtol=1e-5, atol=1e-5)
+    assert np.max(np.abs(g1 - g2)) < 1e-4 * max(1.0, np.max(np.abs(g1)))
