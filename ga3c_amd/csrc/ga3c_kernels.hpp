@@ -249,15 +249,15 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ conv1 + conv2 forward in one launch
-// Workgroup (16 waves) = (sample, upper / lower half of the conv2 output).  The x rows the half needs (56 or
-// 44 padded rows, <= 77 KB) and both filter banks go to LDS once; conv1 runs tile by tile and leaves its
+// Workgroup (16 waves) = (sample, upper / lower half of the conv2 output).  The x rows the half needs (48 or
+// 52 padded rows, <= 72 KB) and both filter banks go to LDS once; conv1 runs tile by tile and leaves its
 // ReLU output in an LDS image of n1 laid out for conv2 (zero border included), conv2 then reads its patches
 // from that image.  n1 never travels to HBM in prediction (TRAIN also stores it: the backward pass needs it).
-// Rows 11,12 of n1 are needed by both halves and are computed twice (+9.5% conv1 MFMAs, identical values).
+// Rows 9,10 of n1 are needed by both halves and are computed twice (+9.5% conv1 MFMAs, identical values).
 // Saves one launch and the 3.6 MB write + 7.2 MB read of n1 per 128 states against conv1_fwd + conv2_fwd.
-constexpr int CS_XROWS = 56;                                  // upper half; lower half uses 44
+constexpr int CS_XROWS = 52;                                  // lower half; upper half uses 48
 constexpr int CS_X_FLOATS = CS_XROWS * C1_PW * 4;             // 19712
-constexpr int CS_N1ROWS = 14;                                 // upper: n1 rows -1..12; lower: 11..22 (12 used)
+constexpr int CS_N1ROWS = 14;                                 // upper: n1 rows -1..10 (12 used); lower: 9..22
 constexpr int CS_N1_FLOATS = CS_N1ROWS * C2_PW * C1;          // 5376
 constexpr int CS_LDS_FLOATS = CS_X_FLOATS + CS_N1_FLOATS + 64 * 64 + 2 * 64 * 64;   // 37376 floats = 149,504 B
 
@@ -273,14 +273,15 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const float* __res
   float* wl2 = wl1 + 64 * 64;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x >> 1, h = blockIdx.x & 1;
-  const int c2r0 = h ? 6 : 0, c2nr = h ? 5 : 6;              // conv2 output rows of this half
-  const int n1r0 = h ? 11 : 0, n1nr = h ? 10 : 13;           // n1 rows it needs
+  // conv2 rows 0..4 | 5..10: then each half has <= 16 conv1 tiles and <= 16 conv2 items, one per wave
+  const int c2r0 = h ? 5 : 0, c2nr = h ? 6 : 5;              // conv2 output rows of this half
+  const int n1r0 = h ? 9 : 0, n1nr = h ? 12 : 11;            // n1 rows it needs (rows 9,10 are computed by both)
   const int n1org = 2 * c2r0 - 1;                            // n1 row held by LDS image row 0
-  const int xr0 = 4 * n1r0 - 2, xnr = 4 * n1nr + 4;          // x rows it needs (56 / 44)
+  const int xr0 = 4 * n1r0 - 2, xnr = 4 * n1nr + 4;          // x rows it needs (48 / 52)
   const float* xb = x + (size_t)b * XS;
   // ---- stage x rows (zero padded), W1, W2; clear the n1 image.  All global loads are issued before the
   // first LDS store, so the block pays one memory round trip.
-  const int npx = xnr * C1_PW;                               // <= 4928 pixels -> at most 5 per thread
+  const int npx = xnr * C1_PW;                               // <= 4576 pixels -> at most 5 per thread
   f32x4 sx[5], sw1, sw2[2];
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
