@@ -285,3 +285,42 @@ def test_batch_row_permutation_properties(nets):
     g2 = net.get_arena(3)
     assert np.allclose(l1, l2, rtol=1e-5, atol=1e-5)
     assert np.max(np.abs(g1 - g2)) < 1e-4 * max(1.0, np.max(np.abs(g1)))
+
+
+def test_network_helper_surface_matches_reference(nets, tmp_path, monkeypatch):
+    """The rest of the reference's Network surface (NetworkVP.py:233-246,259-288): predict_single / predict_p /
+    predict_v, get_global_step, get_variables_names / get_variable_value with the TF variable names, log, and the
+    checkpoint naming + episode-from-filename rule."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    net = nets(6)
+    _, x, a, y = _batch(3, 6, 8)
+    p, v = net.predict_p_and_v(x)
+    assert np.array_equal(net.predict_p(x), p) and np.array_equal(net.predict_v(x), v)
+    assert np.array_equal(net.predict_single(x[1]), p[1])
+    names = net.get_variables_names()
+    assert names == [n + ":0" for n in o.PARAM_ORDER]
+    shapes = o.param_shapes(6)
+    for n in names:
+        assert net.get_variable_value(n).shape == shapes[n[:-2]]
+    w = net.get_variable_value("logits_v/b:0")
+    net.set_variable_value("logits_v/b:0", w + 1.0)
+    assert np.allclose(net.predict_v(x), v + 1.0, atol=1e-6)        # the value head's bias moved by exactly 1
+    net.set_variable_value("logits_v/b:0", w)
+    step = net.get_global_step()
+    net.learning_rate, net.beta = 3e-4, 0.01
+    net.train(x, y, a, x, np.zeros(3, bool), 0)
+    assert net.get_global_step() == step + 1
+    net.log(x, y, a, 17)
+    row = open("logs/test/scalars.csv").read().strip().split(",")
+    assert int(row[0]) == 17 and len(row) == 7
+    net.save(123)
+    assert sorted(f for f in __import__("os").listdir("checkpoints")) == ["test_00000123.npz"]
+    with np.load("checkpoints/test_00000123.npz") as z:
+        assert "dense1/w:0" in z.files and "dense1/w/RMSProp:0" in z.files and "step" in z.files
+        assert z["conv11/w:0"].shape == (8, 8, 4, 16) and int(z["step"]) == step + 1
+    theta = net.get_arena(0)
+    net.set_arena(0, np.zeros_like(theta))
+    monkeypatch.setattr(Config, "LOAD_EPISODE", 0)
+    assert net.load() == 123 and np.array_equal(net.get_arena(0), theta)
