@@ -75,19 +75,14 @@ int main(int argc, char** argv) {
   printf("conv2 single: %.2f us\n", time_us([&](hipEvent_t a, hipEvent_t b) {
     hipExtLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, a, b, 0, n1, w, w + 8192, n2, B); }, st, 20));
   chain("conv2", [&]() { hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, n1, w, w + 8192, n2, B); }, 200);
-  {
-    float *dd1, *gwd, *gbd;
-    CK(hipMalloc(&dd1, (size_t)B * HID * 4)); CK(hipMalloc(&gwd, (size_t)FLAT * HID * 4)); CK(hipMalloc(&gbd, HID * 4));
-    CK(hipMemset(dd1, 0, (size_t)B * HID * 4)); CK(hipMemset(n2, 0, (size_t)B * FLAT * 4));
-    HeadBwdArgs hb; memset(&hb, 0, sizeof hb);
-    for (int gx : {121, 60, 30, 15}) {
-      printf("dense1_dw grid.x=%3d: %.2f us\n", gx, time_us([&](hipEvent_t a, hipEvent_t b) {
-        hipExtLaunchKernelGGL(dense1_dw_kernel, dim3(gx, 2), dim3(256), 0, st, a, b, 0, n2, dd1, gwd, gbd, B, hb); }, st, 20));
-    }
-    float* dn2; CK(hipMalloc(&dn2, (size_t)B * FLAT * 4));
-    for (int gx : {121, 60, 30, 15}) {
-      printf("dense1_dx grid.x=%3d: %.2f us\n", gx, time_us([&](hipEvent_t a, hipEvent_t b) {
-        hipExtLaunchKernelGGL(dense1_dx_kernel, dim3(gx, ((B + 15) / 16 + 3) / 4), dim3(256), 0, st, a, b, 0, dd1, pk, n2, dn2, B); }, st, 20));
+  for (int mt : {1, 2, 4}) {
+    for (int ks : {11, 22}) {
+      const int nb = dense1_fwd_blocks(B, ks, mt);
+      auto l1 = [&](hipEvent_t a, hipEvent_t b) {
+        if (mt == 1) hipExtLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(nb), dim3(256), 0, st, a, b, 0, n2, pk, part, B, ks, 242 / ks);
+        else if (mt == 2) hipExtLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(nb), dim3(256), 0, st, a, b, 0, n2, pk, part, B, ks, 242 / ks);
+        else hipExtLaunchKernelGGL(dense1_fwd_kernel<4>, dim3(nb), dim3(256), 0, st, a, b, 0, n2, pk, part, B, ks, 242 / ks); };
+      printf("dense1_fwd MT=%d KS=%d blocks=%d: %.2f us\n", mt, ks, nb, time_us(l1, st, 20));
     }
   }
   return 0;
