@@ -62,6 +62,7 @@ struct Fwd {   // forward workspace of one lane (device pointers)
   float *x = nullptr, *n1 = nullptr, *n2 = nullptr, *part = nullptr, *d1 = nullptr, *z = nullptr, *p = nullptr,
         *v = nullptr;
   uint8_t* xu8 = nullptr;
+  bool x_u8 = false;   // the staged batch lives in xu8 (uint8 frames) and the conv kernels convert while reading
 };
 
 struct Lane {
@@ -165,15 +166,20 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
   const float* th = net->theta[idx];
+  const void* xin = f.x_u8 ? (const void*)f.xu8 : (const void*)f.x;
   if (net->fused_conv && B <= 160) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
-    if (train)
-      hipLaunchKernelGGL(conv_stack_fwd_kernel<true>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), st, f.x,
-                         th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, f.n1, f.n2, B);
-    else
-      hipLaunchKernelGGL(conv_stack_fwd_kernel<false>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), st, f.x,
-                         th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, f.n1, f.n2, B);
+    const size_t lds = CS_LDS_FLOATS * sizeof(float);
+#define CSTACK(T, U)                                                                                                \
+  hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, th + OFF_W1, th + OFF_B1, \
+                     th + OFF_W2, th + OFF_B2, f.n1, f.n2, B)
+    if (train) { if (f.x_u8) CSTACK(true, true); else CSTACK(true, false); }
+    else { if (f.x_u8) CSTACK(false, true); else CSTACK(false, false); }
+#undef CSTACK
   } else {
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * 7), dim3(256), 0, st, f.x, th + OFF_W1, th + OFF_B1, f.n1, B);
+    if (f.x_u8)
+      hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(B * 7), dim3(256), 0, st, xin, th + OFF_W1, th + OFF_B1, f.n1, B);
+    else
+      hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(B * 7), dim3(256), 0, st, xin, th + OFF_W1, th + OFF_B1, f.n1, B);
     hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
   }
   const int ks = dense_ks(B);
@@ -221,7 +227,10 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
   hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
   const int nch1 = B * 7 < 512 ? B * 7 : 512;  // workgroups = partial slabs
-  hipLaunchKernelGGL(conv1_dw_kernel, dim3(nch1), dim3(256), 0, st, t.f.x, t.dn1, t.slab1, B * 7);
+  if (t.f.x_u8)
+    hipLaunchKernelGGL(conv1_dw_kernel<true>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
+  else
+    hipLaunchKernelGGL(conv1_dw_kernel<false>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.x, t.dn1, t.slab1, B * 7);
   {
     SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
     SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
@@ -316,12 +325,7 @@ int stage_train_inputs(ga3c_net* net, const void* x, bool u8, const float* y_r, 
       memcpy(t.h_in, x, xb);
       HIPCHK(hipMemcpyAsync(dst, t.h_in, xb, hipMemcpyHostToDevice, t.st));
     }
-    if (u8) {
-      const int64_t n4 = (int64_t)xb / 4;
-      int blocks = (int)((n4 + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(u8_to_f32_kernel, dim3(blocks), dim3(256), 0, t.st, t.f.xu8, t.f.x, n4);
-    }
+    t.f.x_u8 = u8;
   }
   float* hy = t.h_in + (size_t)net->maxB * XS;
   float* ha = hy + net->maxB;
@@ -346,7 +350,7 @@ int read_losses(ga3c_net* net, float* losses) {
 }
 
 // rows of a batch gathered from the registered host segment into x (device), on stream st
-int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off, int64_t* d_off, float* x,
+int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off, int64_t* d_off, Fwd& f,
                   hipStream_t st) {
   if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
@@ -360,8 +364,9 @@ int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
   const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  if (u8) hipLaunchKernelGGL(gather_states_kernel<true>, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, x, B);
-  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, x, B);
+  if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, f.xu8, B);
+  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, f.x, B);
+  f.x_u8 = u8;
   HIPCHK(hipGetLastError());
   return GA3C_OK;
 }
@@ -408,10 +413,7 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
       memcpy(L->h_in, x, nb);
       HIPCHK(hipMemcpyAsync(L->f.xu8, L->h_in, nb, hipMemcpyHostToDevice, L->st));
     }
-    const int64_t n4 = (int64_t)nb / 4;
-    int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(blocks), dim3(256), 0, L->st, L->f.xu8, L->f.x, n4);
+    L->f.x_u8 = true;
   } else {
     const size_t nb = (size_t)B * XS * sizeof(float);
     if (is_pinned(x)) {
@@ -420,6 +422,7 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
       memcpy(L->h_in, x, nb);
       HIPCHK(hipMemcpyAsync(L->f.x, L->h_in, nb, hipMemcpyHostToDevice, L->st));
     }
+    L->f.x_u8 = false;
   }
   return finish_predict(net, L, B, p, v, z);
 }
@@ -462,14 +465,17 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   net->cfg = *cfg;
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
   if (net->fused_conv) {
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_fwd_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CS_LDS_FLOATS * sizeof(float)));
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stack_fwd_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CS_LDS_FLOATS * sizeof(float)));
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      delete net;
-      return fail(GA3C_EHIP, "cannot reserve %d bytes of LDS for conv_stack_fwd_kernel: %s", (int)(CS_LDS_FLOATS * sizeof(float)),
-                  hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    const int lds = (int)(CS_LDS_FLOATS * sizeof(float));
+    const void* fns[4] = {reinterpret_cast<const void*>(&conv_stack_fwd_kernel<true, true>),
+                          reinterpret_cast<const void*>(&conv_stack_fwd_kernel<true, false>),
+                          reinterpret_cast<const void*>(&conv_stack_fwd_kernel<false, true>),
+                          reinterpret_cast<const void*>(&conv_stack_fwd_kernel<false, false>)};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        delete net;
+        return fail(GA3C_EHIP, "cannot reserve %d bytes of LDS for conv_stack_fwd_kernel: %s", lds, hipGetErrorString(e));
+      }
     }
   }
   net->A = cfg->num_actions;
@@ -737,7 +743,7 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
   HIPCHK(hipSetDevice(net->cfg.device));
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
-  CHK(launch_gather(net, offsets, batch, u8 != 0, L->h_off, L->d_off, L->f.x, L->st));
+  CHK(launch_gather(net, offsets, batch, u8 != 0, L->h_off, L->d_off, L->f, L->st));
   return finish_predict(net, L, batch, p, v, z);
 }
 
@@ -747,7 +753,7 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
   TrainLane& t = net->tr;
-  CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.d_off, t.f.x, t.st));
+  CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.d_off, t.f, t.st));
   CHK(stage_train_inputs(net, nullptr, false, y_r, a, batch));
   CHK(train_grads(net, batch, beta));
   CHK(train_apply(net, learning_rate));
@@ -759,6 +765,15 @@ int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
   CHK(stage_train_inputs(net, x, false, y_r, a, batch));
+  HIPCHK(hipStreamSynchronize(net->tr.st));
+  return GA3C_OK;
+}
+
+int ga3c_net_upload_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch) {
+  if (!net || !x) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(stage_train_inputs(net, x, true, y_r, a, batch));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
 }
@@ -824,8 +839,12 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
   CHK(sync_all(net));
-  for (int l = 0; l < nlanes; ++l)
-    HIPCHK(hipMemcpy(net->lanes[l]->f.x, net->tr.f.x, (size_t)batch * XS * sizeof(float), hipMemcpyDeviceToDevice));
+  for (int l = 0; l < nlanes; ++l) {
+    Fwd& lf = net->lanes[l]->f;
+    lf.x_u8 = net->tr.f.x_u8;
+    if (lf.x_u8) HIPCHK(hipMemcpy(lf.xu8, net->tr.f.xu8, (size_t)batch * XS, hipMemcpyDeviceToDevice));
+    else HIPCHK(hipMemcpy(lf.x, net->tr.f.x, (size_t)batch * XS * sizeof(float), hipMemcpyDeviceToDevice));
+  }
   int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
@@ -859,12 +878,15 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
 #define TL(kern, grid, ...) hipExtLaunchKernelGGL(kern, grid, dim3(256), 0, t.st, t.ev0, t.ev1, 0, __VA_ARGS__)
   for (int i = 0; i < iters; ++i) {
     if (k == "conv1_fwd") {
-      TL(conv1_fwd_kernel, dim3(B * 7), t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, B);
+      TL(conv1_fwd_kernel<false>, dim3(B * 7), (const void*)t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, B);
     } else if (k == "conv2_fwd") {
       TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "conv_stack_fwd") {
-      hipExtLaunchKernelGGL(conv_stack_fwd_kernel<false>, dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st, t.ev0,
-                            t.ev1, 0, t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B);
+      hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B);
+    } else if (k == "conv_stack_fwd_u8") {
+      hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
+                            t.ev0, t.ev1, 0, (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B);
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
       if (B <= 256)
@@ -874,7 +896,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
         TL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), t.f.n2, net->theta_pk[net->cur], t.f.part, B, ks,
            KSTEPS_DENSE / ks);
     } else if (k == "conv1_dw") {
-      TL(conv1_dw_kernel, dim3(B * 7 < 512 ? B * 7 : 512), t.f.x, t.dn1, t.slab1, B * 7);
+      TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {
       TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {

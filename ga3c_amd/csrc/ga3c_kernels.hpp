@@ -54,6 +54,20 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ------------------------------------------------------------------ state input: f32 NHWC or the uint8 frames
+// The kernels that read the states take them either as the f32 tensor the reference feeds (NetworkVP.py:252) or as
+// the uint8 frames they were made from (Environment.py:59-60), converting `k/128 - 1` while staging (exact in f32),
+// so uint8 batches never exist as f32 in HBM.
+template <bool U8>
+__device__ __forceinline__ f32x4 load_px(const void* __restrict__ x, size_t sample, int pix) {
+  if (U8) {
+    const unsigned k = reinterpret_cast<const unsigned*>(x)[sample * (XS / 4) + pix];
+    return (f32x4){(float)(k & 255u) * 0.0078125f - 1.0f, (float)((k >> 8) & 255u) * 0.0078125f - 1.0f,
+                   (float)((k >> 16) & 255u) * 0.0078125f - 1.0f, (float)(k >> 24) * 0.0078125f - 1.0f};
+  }
+  return ld4(reinterpret_cast<const float*>(x) + sample * XS + (size_t)pix * 4);
+}
+
 // ------------------------------------------------------------------ input conversion
 // uint8 frames -> f32 `k/128 - 1` (Environment.py:60).  Exact in f32: k/128 is exact and so is the subtraction.
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
@@ -94,6 +108,18 @@ __global__ __launch_bounds__(256) void gather_states_kernel(const uint8_t* __res
   }
 }
 
+// Same gather, uint8 frames kept as uint8 (28,224 B per state): the conv kernels convert while staging.
+__global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ host_base,
+                                                        const int64_t* __restrict__ offsets, uint8_t* __restrict__ xu8,
+                                                        int B) {
+  constexpr int CHUNKS = XS / 16;
+  const int64_t total = (int64_t)B * CHUNKS;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / CHUNKS), c = (int)(i - (int64_t)b * CHUNKS);
+    reinterpret_cast<uint4*>(xu8)[i] = *reinterpret_cast<const uint4*>(host_base + offsets[b] + (size_t)c * 16);
+  }
+}
+
 // ------------------------------------------------------------------ conv1 forward
 // n1[m][o] = relu(b1[o] + sum_k patch(m)[k] W1[k][o]),  m = (b*21+i)*21+j, k = (u*8+v)*4+c.
 // Implicit GEMM M = B*441, K = 256, N = 16.  im2col re-reads every input pixel 4x; served from L2 that
@@ -106,7 +132,8 @@ constexpr int C1_RIN = 4 * C1_HB + 4;       // padded input rows per band
 constexpr int C1_PW = 88;                   // padded input width (2 left, 2 right)
 constexpr int C1_LDS_FLOATS = C1_RIN * C1_PW * 4 + 64 * 64;
 
-__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <bool U8>
+__global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ n1,
                                                            int B) {
   __shared__ __attribute__((aligned(16))) float lds[C1_LDS_FLOATS];
@@ -114,7 +141,6 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const float* __restri
   float* wl = lds + C1_RIN * C1_PW * 4;     // [j = s*4+t][lane = g*16+r] = W1[16s+4g+t][r]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x / 7, band = blockIdx.x - b * 7;
-  const float* xb = x + (size_t)b * XS;
   const int y_base = 4 * C1_HB * band - 2;  // image row of padded band row 0
   // band rows -> LDS (zero fill outside the image)
   f32x4 stage[6];
@@ -124,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const float* __restri
     const int row = idx / C1_PW, col = idx - row * C1_PW;
     const int yy = y_base + row, xx = col - 2;
     const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-    stage[i] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
+    stage[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
   }
   f32x4 wstage[4];
 #pragma unroll
@@ -261,8 +287,8 @@ constexpr int CS_N1ROWS = 14;                                 // upper: n1 rows 
 constexpr int CS_N1_FLOATS = CS_N1ROWS * C2_PW * C1;          // 5376
 constexpr int CS_LDS_FLOATS = CS_X_FLOATS + CS_N1_FLOATS + 64 * 64 + 2 * 64 * 64;   // 37376 floats = 149,504 B
 
-template <bool TRAIN>
-__global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+template <bool TRAIN, bool U8>
+__global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w1,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, float* __restrict__ n1,
                                                              float* __restrict__ n2, int B) {
@@ -278,7 +304,6 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const float* __res
   const int n1r0 = h ? 9 : 0, n1nr = h ? 12 : 11;            // n1 rows it needs (rows 9,10 are computed by both)
   const int n1org = 2 * c2r0 - 1;                            // n1 row held by LDS image row 0
   const int xr0 = 4 * n1r0 - 2, xnr = 4 * n1nr + 4;          // x rows it needs (48 / 52)
-  const float* xb = x + (size_t)b * XS;
   // ---- stage x rows (zero padded), W1, W2; clear the n1 image.  All global loads are issued before the
   // first LDS store, so the block pays one memory round trip.
   const int npx = xnr * C1_PW;                               // <= 4576 pixels -> at most 5 per thread
@@ -289,7 +314,7 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const float* __res
     const int row = idx / C1_PW, col = idx - row * C1_PW;
     const int yy = xr0 + row, xx = col - 2;
     const bool ok = idx < npx && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-    sx[i] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
+    sx[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
   }
   sw1 = ld4(w1 + 4 * threadIdx.x);                           // W1[256][16] = 1024 float4
   sw2[0] = ld4(w2 + 4 * threadIdx.x);                        // W2[256][32] = 2048 float4
@@ -1012,7 +1037,8 @@ constexpr int SLAB1 = 256 * 16 + 16;
 constexpr int C1DW_IMG = C1_RIN * C1_PW * 4;     // 5632 floats
 constexpr int C1DW_DN = 64 * C1;                 // 1024 floats
 
-__global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const float* __restrict__ x, const float* __restrict__ dn1,
+template <bool U8>
+__global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict__ x, const float* __restrict__ dn1,
                                                           float* __restrict__ part, int nunits) {
   __shared__ __attribute__((aligned(16))) float lds[C1DW_IMG + C1DW_DN];
   float* img = lds;
@@ -1023,7 +1049,6 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const float* __restric
   f32x4 simg[6], sdn;
   auto fetch = [&](int unit) {
     const int b = unit / 7, band = unit - b * 7;
-    const float* xb = x + (size_t)b * XS;
     const int y_base = 4 * C1_HB * band - 2;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -1031,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const float* __restric
       const int row = idx / C1_PW, col = idx - row * C1_PW;
       const int yy = y_base + row, xx = col - 2;
       const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-      simg[i] = ok ? ld4(xb + (yy * IMG + xx) * 4) : zero4();
+      simg[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
     }
     const float* db = dn1 + ((size_t)b * P1 + band * C1_HB * O1) * C1;
     sdn = threadIdx.x < C1_HB * O1 * C1 / 4 ? ld4(db + 4 * threadIdx.x) : zero4();   // 252 float4, slot 63 zero

@@ -75,7 +75,8 @@ int ga3c_net_set_step(ga3c_net* net, int64_t step);
  * p f32[B,A] (softmax_p), v f32[B] (logits_v); z f32[B,A] (logits_p) if not NULL. */
 int ga3c_net_predict(ga3c_net* net, const float* x, int32_t batch, float* p, float* v, float* z);
 /* Same, states shipped as the uint8 frames of Environment._preprocess before its
- * `/128 - 1` (Environment.py:59-60); the conversion runs on the GPU, bit-identically. */
+ * `/128 - 1` (Environment.py:59-60); they stay uint8 in HBM and the conv kernels convert while
+ * reading them, bit-identically to the f32 path. */
 int ga3c_net_predict_u8(ga3c_net* net, const uint8_t* x, int32_t batch, float* p, float* v, float* z);
 
 /* train (NetworkVP.py:254-257 = sess.run(train_op)): forward, loss, backward,
@@ -96,6 +97,7 @@ int ga3c_net_apply_grads(ga3c_net* net, float learning_rate);
 /* Device-resident path (inputs already in HBM; what bench.py times).
  * upload stages a batch into the train lane (y_r / a may be NULL for predict-only use). */
 int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch);
+int ga3c_net_upload_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch);  /* same, uint8 frames */
 int ga3c_net_predict_resident(ga3c_net* net, int32_t batch);   /* async on the train lane's stream */
 int ga3c_net_train_resident(ga3c_net* net, int32_t batch, float learning_rate, float beta);
 int ga3c_net_sync(ga3c_net* net);
