@@ -187,6 +187,10 @@ class Network:
                   "ga3c_net_register_host")
         self._transport_u8 = transport.state_bytes == nat.STATE_FLOATS
 
+    def unregister_transport(self):
+        """Unpin the segment (call before the transport is unmapped)."""
+        nat.check(self._lib.ga3c_net_unregister_host(self._h), "ga3c_net_unregister_host")
+
     def predict_offsets(self, offsets):
         """offsets: int64[B] byte offsets of the states inside the registered segment."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

@@ -171,6 +171,9 @@ class Server:
             self.remove_trainer()
         if self.stats.is_alive():
             self.stats.terminate()
+        if self.zero_copy:
+            self.model.unregister_transport()       # unpin before the segment is unmapped
+            self.zero_copy = False
         self.transport.close()
 
     @staticmethod
