@@ -212,6 +212,22 @@ def main():
 
     net.close()
 
+    # ---- Hogwild trainers: the reference's default NT = 2 trainer threads update shared weights unlocked (Server.py:132-134)
+    if rank == 0 and world == 1:
+        hog = Network("gpu:%d" % local_rank, "bench_hogwild", A, (84, 84, 4), max_batch=B, predict_lanes=1, train_lanes=2)
+        nat.check(hog._lib.ga3c_net_upload(hog._h, nat.ptr(x), nat.ptr(y_r), nat.ptr(act), B), "upload")
+        ms = nat.C.c_float()
+        res = {}
+        for nl in (1, 2):
+            nat.check(hog._lib.ga3c_net_time_train_lanes(hog._h, B, max(W, 1), nl, lr, beta, nat.C.byref(ms)), "warmup")
+            torch.cuda.synchronize()
+            nat.check(hog._lib.ga3c_net_time_train_lanes(hog._h, B, K, nl, lr, beta, nat.C.byref(ms)), "time_train_lanes")
+            res[str(nl)] = K / (ms.value * 1e-3)
+        out["train"]["hogwild_lanes"] = dict(res, unit="steps/s", note="Config.HOGWILD: NT train lanes update the weights "
+                                             "concurrently and unlocked like the reference's trainer threads; the headline "
+                                             "train figure above is the synchronous single-lane mode")
+        hog.close()
+
     # ---- whole engine, BASELINE configs[1]/[2] shape: agents -> shm transport -> ThreadPredictor / ThreadTrainer -> HIP
     if rank == 0 and world == 1 and args.e2e_seconds > 0:
         from Server import Server

@@ -76,5 +76,7 @@ class Config:
     STATE_TRANSPORT = 'u8'              # 'u8': ship uint8 frames, convert on GPU; 'f32': ship f32 states
     SYNTHETIC_EPISODE_LENGTH = 1000
     TRAIN_ROWS_MAX = 0                  # capacity of one train call; 0 = derive from the batch knobs
+    HOGWILD = False                     # True: TRAINERS train lanes update the weights concurrently and unlocked,
+                                        # as the reference's trainer threads do; False: synchronous steps (default)
     ZERO_COPY = True                    # GPU gathers states straight from the registered shm transport
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often

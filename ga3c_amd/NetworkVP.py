@@ -49,7 +49,7 @@ def _device_ordinal(device):
 
 
 class Network:
-    def __init__(self, device, model_name, num_actions, state_dim, max_batch=None, predict_lanes=None):
+    def __init__(self, device, model_name, num_actions, state_dim, max_batch=None, predict_lanes=None, train_lanes=None):
         self.device = device
         self.model_name = model_name
         self.num_actions = int(num_actions)
@@ -79,6 +79,9 @@ class Network:
         cfg.min_policy = Config.MIN_POLICY
         cfg.grad_clip_norm = Config.GRAD_CLIP_NORM
         cfg.predict_lanes = int(predict_lanes or max(1, Config.PREDICTORS))
+        if train_lanes is None:
+            train_lanes = max(1, Config.TRAINERS) if Config.HOGWILD else 1
+        cfg.train_lanes = int(train_lanes)
         handle = C.c_void_p()
         nat.check(self._lib.ga3c_net_create(C.byref(cfg), C.byref(handle)), "ga3c_net_create")
         self._h = handle

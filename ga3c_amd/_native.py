@@ -28,7 +28,7 @@ class NetConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_actions", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_uint32),
                 ("rmsprop_decay", C.c_float), ("rmsprop_momentum", C.c_float), ("rmsprop_epsilon", C.c_float),
                 ("log_epsilon", C.c_float), ("min_policy", C.c_float), ("grad_clip_norm", C.c_float),
-                ("predict_lanes", C.c_int32), ("reserved", C.c_int32)]
+                ("predict_lanes", C.c_int32), ("train_lanes", C.c_int32)]
 
 
 class ShmConfig(C.Structure):
@@ -64,6 +64,7 @@ HIP_SIGNATURES = {
     "ga3c_net_sync": (C.c_int, [C.c_void_p]),
     "ga3c_net_time_resident": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_time_predict_lanes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, f32p]),
+    "ga3c_net_time_train_lanes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_time_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, f32p]),
     "ga3c_net_fetch": (C.c_int, [C.c_void_p, C.c_char_p, f32p, C.c_int64]),
     "ga3c_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),

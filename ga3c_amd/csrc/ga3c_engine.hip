@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -87,6 +88,8 @@ struct TrainLane {
   float* h_out = nullptr;   // pinned: p | v | z | losses
   int64_t* h_off = nullptr;
   int64_t* d_off = nullptr;
+  float* grad = nullptr;    // this lane's gradient arena (lane 0: net->grad, the buffer RCCL all-reduces)
+  bool owns_grad = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -108,8 +111,11 @@ struct ga3c_net {
   std::shared_mutex wmu;   // shared: a forward pass picking/reading theta[cur]; unique: the optimizer flip
   std::vector<Lane*> lanes;
   std::atomic<unsigned> rr{0};
-  TrainLane tr;
-  int64_t step = 0;
+  TrainLane tr;                        // train lane 0 (the only one in synchronous mode)
+  std::vector<TrainLane*> xtr;         // extra train lanes: Hogwild mode (cfg.train_lanes >= 2), as the reference's NT threads
+  bool hogwild = false;
+  std::atomic<unsigned> trr{0};
+  std::atomic<int64_t> step{0};
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
@@ -206,11 +212,10 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   return GA3C_OK;
 }
 
-int launch_backward(ga3c_net* net, const float* th, int B) {
-  TrainLane& t = net->tr;
+int launch_backward(ga3c_net* net, TrainLane& t, const float* th, int B) {
   const int A = net->A;
   hipStream_t st = t.st;
-  float* g = net->grad;
+  float* g = t.grad;
   HeadBwdArgs hb;
   hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
   hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV; hb.g_bv = g + OFF_BV; hb.losses = t.losses;
@@ -240,18 +245,18 @@ int launch_backward(ga3c_net* net, const float* th, int B) {
   return GA3C_OK;
 }
 
-int launch_rmsprop(ga3c_net* net, const float* tin, float* tout, float* pk_out, float lr, hipStream_t st) {
+int launch_rmsprop(ga3c_net* net, const float* grad, float* scales, const float* tin, float* tout, float* pk_out,
+                   float lr, hipStream_t st) {
   const bool clip = net->cfg.flags & GA3C_FLAG_GRAD_CLIP;
   const bool mom = net->cfg.rmsprop_momentum != 0.0f;
   const float omr = 1.0f - net->cfg.rmsprop_decay;
   const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
   if (clip)
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(10), dim3(256), 0, st, net->grad, net->tt, net->cfg.grad_clip_norm,
-                       net->tr.scales);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(10), dim3(256), 0, st, grad, net->tt, net->cfg.grad_clip_norm, scales);
 #define RMS(C, M)                                                                                                \
   hipLaunchKernelGGL((rmsprop_kernel<C, M>), dim3(blocks), dim3(256), 0, st, tin, tout, net->ms, net->mom,        \
-                     net->grad, net->n, lr, omr, net->cfg.rmsprop_momentum, net->cfg.rmsprop_epsilon, net->tt,    \
-                     net->tr.scales, pk_out)
+                     grad, net->n, lr, omr, net->cfg.rmsprop_momentum, net->cfg.rmsprop_epsilon, net->tt, scales,  \
+                     pk_out)
   if (clip && mom) RMS(true, true);
   else if (clip) RMS(true, false);
   else if (mom) RMS(false, true);
@@ -280,22 +285,30 @@ int lane_forward(ga3c_net* net, Lane& L, int B) {
   return GA3C_OK;
 }
 
-// gradients of the batch staged in the train lane -> net->grad (train lane mutex held by caller)
-int train_grads(ga3c_net* net, int B, float beta) {
+// gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller)
+int train_grads(ga3c_net* net, TrainLane& t, int B, float beta) {
   int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    idx = net->cur;   // only this lane's stream ever flips it, and that is ordered behind us
+    idx = net->cur;   // synchronous mode: only lane 0's stream ever flips it, and that is ordered behind us
   }
-  CHK(launch_forward(net, net->tr.f, idx, B, net->tr.st, true, &net->tr, beta));
-  CHK(launch_backward(net, net->theta[idx], B));
+  CHK(launch_forward(net, t.f, idx, B, t.st, true, &t, beta));
+  CHK(launch_backward(net, t, net->theta[idx], B));
   return GA3C_OK;
 }
 
-int train_apply(ga3c_net* net, float lr) {
-  TrainLane& t = net->tr;
+int train_apply(ga3c_net* net, TrainLane& t, float lr) {
+  if (net->hogwild) {
+    // The reference's NT trainer threads run sess.run(train_op) concurrently on shared variables without locking
+    // (Server.py:132-134, TF use_locking=False): every lane updates theta / ms in place from its own stream; reads by
+    // other lanes may see a step half applied, and two optimizer kernels may race on an element.
+    const int idx = net->cur;
+    CHK(launch_rmsprop(net, t.grad, t.scales, net->theta[idx], net->theta[idx], net->theta_pk[idx], lr, t.st));
+    net->step.fetch_add(1);
+    return GA3C_OK;
+  }
   if (net->comm && net->world > 1)
-    NCCLCHK(ncclAllReduce(net->grad, net->grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
+    NCCLCHK(ncclAllReduce(t.grad, t.grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
   std::unique_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->cur, other = 1 - idx;
   // Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only
@@ -306,15 +319,14 @@ int train_apply(ga3c_net* net, float lr) {
       L->dirty[other] = false;
     }
   }
-  CHK(launch_rmsprop(net, net->theta[idx], net->theta[other], net->theta_pk[other], lr, t.st));
+  CHK(launch_rmsprop(net, t.grad, t.scales, net->theta[idx], net->theta[other], net->theta_pk[other], lr, t.st));
   net->ready_recorded[other] = false;   // a lane that needs this buffer records theta_ready itself (lane_forward)
   net->cur = other;
-  net->step += 1;
+  net->step.fetch_add(1);
   return GA3C_OK;
 }
 
-int stage_train_inputs(ga3c_net* net, const void* x, bool u8, const float* y_r, const float* a, int B) {
-  TrainLane& t = net->tr;
+int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, const float* y_r, const float* a, int B) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   if (x) {
     const size_t xb = (size_t)B * XS * (u8 ? 1 : sizeof(float));
@@ -340,8 +352,7 @@ int stage_train_inputs(ga3c_net* net, const void* x, bool u8, const float* y_r, 
   return GA3C_OK;
 }
 
-int read_losses(ga3c_net* net, float* losses) {
-  TrainLane& t = net->tr;
+int read_losses(ga3c_net* net, TrainLane& t, float* losses) {
   float* hl = t.h_out;
   HIPCHK(hipMemcpyAsync(hl, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
   HIPCHK(hipStreamSynchronize(t.st));
@@ -427,9 +438,75 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
   return finish_predict(net, L, B, p, v, z);
 }
 
+// Lane for one train call.  Synchronous mode: lane 0, callers queue on its mutex.  Hogwild mode: any free lane.
+// Returned locked.
+TrainLane* take_train_lane(ga3c_net* net) {
+  if (!net->hogwild || net->xtr.empty()) {
+    net->tr.mu.lock();
+    return &net->tr;
+  }
+  const size_t n = net->xtr.size() + 1;
+  const unsigned start = net->trr.fetch_add(1);
+  for (size_t k = 0; k < n; ++k) {
+    const size_t i = (start + k) % n;
+    TrainLane* c = i == 0 ? &net->tr : net->xtr[i - 1];
+    if (c->mu.try_lock()) return c;
+  }
+  const size_t i = start % n;
+  TrainLane* c = i == 0 ? &net->tr : net->xtr[i - 1];
+  c->mu.lock();
+  return c;
+}
+
+int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
+  const int maxB = net->maxB, A = net->A;
+  HIPCHK(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
+  CHK(alloc_fwd(t.f, maxB, A));
+  CHK(dmalloc(&t.yr, maxB));
+  CHK(dmalloc(&t.act, (size_t)maxB * A));
+  CHK(dmalloc(&t.dz, (size_t)maxB * A));
+  CHK(dmalloc(&t.dv, maxB));
+  CHK(dmalloc(&t.lossrow, (size_t)maxB * 3));
+  CHK(dmalloc(&t.dd1, (size_t)maxB * HID));
+  CHK(dmalloc(&t.dn2, (size_t)maxB * FLAT));
+  CHK(dmalloc(&t.dn1, (size_t)maxB * N1S));
+  CHK(dmalloc(&t.slab2, (size_t)256 * SLAB2));   // conv2_dw: at most 256 sample groups
+  CHK(dmalloc(&t.slab1, (size_t)512 * SLAB1));   // conv1_dw: at most 512 workgroups
+  CHK(dmalloc(&t.losses, 4));
+  CHK(dmalloc(&t.scales, 16));
+  if (shared_grad) {
+    t.grad = shared_grad;
+  } else {
+    CHK(dmalloc(&t.grad, (size_t)net->n));
+    t.owns_grad = true;
+  }
+  HIPCHK(hipHostMalloc((void**)&t.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&t.h_out, ((size_t)maxB * (2 * A + 1) + 4) * sizeof(float), hipHostMallocDefault));
+  HIPCHK(hipEventCreate(&t.ev0));
+  HIPCHK(hipEventCreate(&t.ev1));
+  HIPCHK(hipHostMalloc((void**)&t.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
+  HIPCHK(hipMalloc((void**)&t.d_off, (size_t)maxB * sizeof(int64_t)));
+  return GA3C_OK;
+}
+
+void free_train_lane(TrainLane& t) {
+  free_fwd(t.f);
+  for (float* p : {t.yr, t.act, t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.losses, t.scales})
+    if (p) (void)hipFree(p);
+  if (t.owns_grad && t.grad) (void)hipFree(t.grad);
+  if (t.h_in) (void)hipHostFree(t.h_in);
+  if (t.h_out) (void)hipHostFree(t.h_out);
+  if (t.h_off) (void)hipHostFree(t.h_off);
+  if (t.d_off) (void)hipFree(t.d_off);
+  if (t.ev0) (void)hipEventDestroy(t.ev0);
+  if (t.ev1) (void)hipEventDestroy(t.ev1);
+  if (t.st) (void)hipStreamDestroy(t.st);
+}
+
 int sync_all(ga3c_net* net) {
   for (Lane* L : net->lanes) HIPCHK(hipStreamSynchronize(L->st));
   HIPCHK(hipStreamSynchronize(net->tr.st));
+  for (TrainLane* t : net->xtr) HIPCHK(hipStreamSynchronize(t->st));
   return GA3C_OK;
 }
 
@@ -530,27 +607,14 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     TRYHIP(hipHostMalloc((void**)&L->h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
     TRYHIP(hipMalloc((void**)&L->d_off, (size_t)maxB * sizeof(int64_t)));
   }
-  TrainLane& t = net->tr;
-  TRYHIP(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
-  TRY(alloc_fwd(t.f, maxB, A));
-  TRY(dmalloc(&t.yr, maxB));
-  TRY(dmalloc(&t.act, (size_t)maxB * A));
-  TRY(dmalloc(&t.dz, (size_t)maxB * A));
-  TRY(dmalloc(&t.dv, maxB));
-  TRY(dmalloc(&t.lossrow, (size_t)maxB * 3));
-  TRY(dmalloc(&t.dd1, (size_t)maxB * HID));
-  TRY(dmalloc(&t.dn2, (size_t)maxB * FLAT));
-  TRY(dmalloc(&t.dn1, (size_t)maxB * N1S));
-  TRY(dmalloc(&t.slab2, (size_t)256 * SLAB2));   // conv2_dw: at most 256 sample groups
-  TRY(dmalloc(&t.slab1, (size_t)512 * SLAB1));   // conv1_dw: at most 512 workgroups
-  TRY(dmalloc(&t.losses, 4));
-  TRY(dmalloc(&t.scales, 16));
-  TRYHIP(hipHostMalloc((void**)&t.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
-  TRYHIP(hipHostMalloc((void**)&t.h_out, ((size_t)maxB * (2 * A + 1) + 4) * sizeof(float), hipHostMallocDefault));
-  TRYHIP(hipEventCreate(&t.ev0));
-  TRYHIP(hipEventCreate(&t.ev1));
-  TRYHIP(hipHostMalloc((void**)&t.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
-  TRYHIP(hipMalloc((void**)&t.d_off, (size_t)maxB * sizeof(int64_t)));
+  TRY(alloc_train_lane(net, net->tr, net->grad));
+  net->hogwild = cfg->train_lanes >= 2;
+  for (int i = 1; i < cfg->train_lanes && i < 8; ++i) {
+    TrainLane* t = new (std::nothrow) TrainLane();
+    if (!t) { ga3c_net_destroy(net); return fail(GA3C_EINVAL, "out of host memory"); }
+    net->xtr.push_back(t);
+    TRY(alloc_train_lane(net, *t, nullptr));
+  }
   TRYHIP(hipDeviceSynchronize());
 #undef TRY
 #undef TRYHIP
@@ -574,18 +638,12 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (L->st) (void)hipStreamDestroy(L->st);
     delete L;
   }
-  TrainLane& t = net->tr;
-  free_fwd(t.f);
-  for (float* p : {t.yr, t.act, t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.losses, t.scales})
-    if (p) (void)hipFree(p);
-  if (t.h_in) (void)hipHostFree(t.h_in);
-  if (t.h_out) (void)hipHostFree(t.h_out);
-  if (t.h_off) (void)hipHostFree(t.h_off);
-  if (t.d_off) (void)hipFree(t.d_off);
+  free_train_lane(net->tr);
+  for (TrainLane* t : net->xtr) {
+    free_train_lane(*t);
+    delete t;
+  }
   if (net->reg_host) (void)hipHostUnregister(net->reg_host);
-  if (t.ev0) (void)hipEventDestroy(t.ev0);
-  if (t.ev1) (void)hipEventDestroy(t.ev1);
-  if (t.st) (void)hipStreamDestroy(t.st);
   for (int i = 0; i < 2; ++i) {
     if (net->theta[i]) (void)hipFree(net->theta[i]);
     if (net->theta_pk[i]) (void)hipFree(net->theta_pk[i]);
@@ -647,15 +705,13 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
 
 int ga3c_net_get_step(ga3c_net* net, int64_t* step) {
   if (!net || !step) return fail(GA3C_EINVAL, "null argument");
-  std::shared_lock<std::shared_mutex> lk(net->wmu);
-  *step = net->step;
+  *step = net->step.load();
   return GA3C_OK;
 }
 
 int ga3c_net_set_step(ga3c_net* net, int64_t step) {
   if (!net) return fail(GA3C_EINVAL, "null argument");
-  std::unique_lock<std::shared_mutex> lk(net->wmu);
-  net->step = step;
+  net->step.store(step);
   return GA3C_OK;
 }
 
@@ -672,16 +728,16 @@ int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, cons
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, false, y_r, a, batch));
-  CHK(train_grads(net, batch, beta));
-  return read_losses(net, losses);
+  CHK(stage_train_inputs(net, net->tr, x, false, y_r, a, batch));
+  CHK(train_grads(net, net->tr, batch, beta));
+  return read_losses(net, net->tr, losses);
 }
 
 int ga3c_net_apply_grads(ga3c_net* net, float learning_rate) {
   if (!net) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(train_apply(net, learning_rate));
+  CHK(train_apply(net, net->tr, learning_rate));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
 }
@@ -690,22 +746,24 @@ int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float*
                    float learning_rate, float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, false, y_r, a, batch));
-  CHK(train_grads(net, batch, beta));
-  CHK(train_apply(net, learning_rate));
-  return read_losses(net, losses);
+  TrainLane* t = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
+  CHK(stage_train_inputs(net, *t, x, false, y_r, a, batch));
+  CHK(train_grads(net, *t, batch, beta));
+  CHK(train_apply(net, *t, learning_rate));
+  return read_losses(net, *t, losses);
 }
 
 int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch,
                       float learning_rate, float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, true, y_r, a, batch));
-  CHK(train_grads(net, batch, beta));
-  CHK(train_apply(net, learning_rate));
-  return read_losses(net, losses);
+  TrainLane* t = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
+  CHK(stage_train_inputs(net, *t, x, true, y_r, a, batch));
+  CHK(train_grads(net, *t, batch, beta));
+  CHK(train_apply(net, *t, learning_rate));
+  return read_losses(net, *t, losses);
 }
 
 int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes) {
@@ -751,20 +809,21 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
                           int32_t batch, float learning_rate, float beta, float* losses) {
   if (!net || !offsets || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
-  TrainLane& t = net->tr;
+  TrainLane* tp = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
+  TrainLane& t = *tp;
   CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.d_off, t.f, t.st));
-  CHK(stage_train_inputs(net, nullptr, false, y_r, a, batch));
-  CHK(train_grads(net, batch, beta));
-  CHK(train_apply(net, learning_rate));
-  return read_losses(net, losses);
+  CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
+  CHK(train_grads(net, t, batch, beta));
+  CHK(train_apply(net, t, learning_rate));
+  return read_losses(net, t, losses);
 }
 
 int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch) {
   if (!net || !x) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, false, y_r, a, batch));
+  CHK(stage_train_inputs(net, net->tr, x, false, y_r, a, batch));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
 }
@@ -773,7 +832,7 @@ int ga3c_net_upload_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const 
   if (!net || !x) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(stage_train_inputs(net, x, true, y_r, a, batch));
+  CHK(stage_train_inputs(net, net->tr, x, true, y_r, a, batch));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
 }
@@ -798,8 +857,8 @@ int ga3c_net_train_resident(ga3c_net* net, int32_t batch, float learning_rate, f
   if (!net) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(train_grads(net, batch, beta));
-  return train_apply(net, learning_rate);
+  CHK(train_grads(net, net->tr, batch, beta));
+  return train_apply(net, net->tr, learning_rate);
 }
 
 int ga3c_net_sync(ga3c_net* net) {
@@ -820,8 +879,8 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
     if (mode == 0) {
       CHK(resident_predict_locked(net, batch));
     } else {
-      CHK(train_grads(net, batch, beta));
-      CHK(train_apply(net, learning_rate));
+      CHK(train_grads(net, net->tr, batch, beta));
+      CHK(train_apply(net, net->tr, learning_rate));
     }
   }
   HIPCHK(hipEventRecord(t.ev1, t.st));
@@ -856,6 +915,37 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
     CHK(launch_forward(net, L->f, idx, batch, L->st, false, nullptr, 0.f));
   }
   for (int l = 0; l < nlanes; ++l) HIPCHK(hipStreamSynchronize(net->lanes[l]->st));
+  *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  return GA3C_OK;
+}
+
+int ga3c_net_time_train_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float learning_rate,
+                              float beta, float* elapsed_ms) {
+  // `iters` resident train steps dealt round-robin to `nlanes` train lanes of a Hogwild net (the NT trainer threads of
+  // Config.TRAINERS); every lane gets a copy of the batch uploaded with ga3c_net_upload[_u8].
+  if (!net || !elapsed_ms) return fail(GA3C_EINVAL, "null argument");
+  if (iters < 1 || nlanes < 1 || nlanes > (int)net->xtr.size() + 1) return fail(GA3C_EINVAL, "bad iters/nlanes");
+  if (nlanes > 1 && !net->hogwild) return fail(GA3C_ESTATE, "net was not created with train_lanes >= 2");
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "bad batch");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  CHK(sync_all(net));
+  TrainLane& t0 = net->tr;
+  for (int l = 1; l < nlanes; ++l) {
+    TrainLane& t = *net->xtr[l - 1];
+    t.f.x_u8 = t0.f.x_u8;
+    if (t.f.x_u8) HIPCHK(hipMemcpy(t.f.xu8, t0.f.xu8, (size_t)batch * XS, hipMemcpyDeviceToDevice));
+    else HIPCHK(hipMemcpy(t.f.x, t0.f.x, (size_t)batch * XS * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(t.yr, t0.yr, (size_t)batch * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(t.act, t0.act, (size_t)batch * net->A * sizeof(float), hipMemcpyDeviceToDevice));
+  }
+  const auto h0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) {
+    TrainLane& t = (i % nlanes) == 0 ? net->tr : *net->xtr[(i % nlanes) - 1];
+    CHK(train_grads(net, t, batch, beta));
+    CHK(train_apply(net, t, learning_rate));
+  }
+  CHK(sync_all(net));
   *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   return GA3C_OK;
 }
@@ -940,7 +1030,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2);
     } else if (k == "rmsprop") {
       const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
-      TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->cur], net->ms, net->mom, net->grad, net->n,
+      TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->cur], net->ms, net->mom, t.grad, net->n,
          0.0f, 1.0f - net->cfg.rmsprop_decay, 0.0f, net->cfg.rmsprop_epsilon, net->tt, t.scales,
          net->theta_pk[net->cur]);
     } else {

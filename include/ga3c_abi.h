@@ -50,7 +50,9 @@ typedef struct ga3c_net_config {
   float min_policy;        /* Config.MIN_POLICY      (0.0) */
   float grad_clip_norm;    /* Config.GRAD_CLIP_NORM  (40.0), used with GA3C_FLAG_GRAD_CLIP */
   int32_t predict_lanes;   /* concurrent prediction lanes (>=1; 0 -> 2) */
-  int32_t reserved;
+  int32_t train_lanes;     /* 0/1: synchronous train steps on one lane (default).  >= 2: Hogwild -- that many train
+                              lanes update the weights in place from their own streams, concurrently and unlocked, as
+                              the reference's NT trainer threads do (Server.py:132-134); not combinable with RCCL */
 } ga3c_net_config;
 
 const char* ga3c_last_error(void);
@@ -108,6 +110,10 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
 /* `iters` resident prediction steps dealt round-robin over `nlanes` prediction lanes (the NP predictor threads of
  * Config.PREDICTORS, each with its own HIP stream); host wall-clock from first launch to all lanes drained. */
 int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float* elapsed_ms);
+/* `iters` resident train steps dealt round-robin over `nlanes` train lanes of a net created with train_lanes >= 2
+ * (nlanes = 1 works on any net); host wall-clock from the first launch to all lanes drained. */
+int ga3c_net_time_train_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float learning_rate,
+                              float beta, float* elapsed_ms);
 /* Same bracket around ONE kernel of the step (name as in DESIGN.md, e.g. "conv1_fwd"). */
 int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32_t iters,
                          float* elapsed_ms);

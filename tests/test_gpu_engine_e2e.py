@@ -143,3 +143,49 @@ def test_concurrent_predictors_and_trainer_on_one_network():
         assert np.all(np.isfinite(net.get_arena(0)))
     finally:
         net.close()
+
+
+@pytest.mark.timeout(120)
+def test_hogwild_train_lanes():
+    """train_lanes >= 2 = the reference's unlocked NT trainer threads.  Called from ONE thread the lanes take turns and
+    the result is bit-identical to the synchronous net; called from two threads the steps overlap on the GPU."""
+    import threading
+    import time
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    rng = np.random.default_rng(5)
+    xk = rng.integers(0, 256, size=(32, 84, 84, 4), dtype=np.uint8)
+    y = rng.uniform(-1, 1, 32)
+    a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, 32)]
+    sync = Network("gpu:0", "s", 6, (84, 84, 4), max_batch=32, predict_lanes=1, train_lanes=1)
+    hog = Network("gpu:0", "h", 6, (84, 84, 4), max_batch=32, predict_lanes=1, train_lanes=2)
+    try:
+        for net in (sync, hog):
+            net.learning_rate, net.beta = 3e-4, 0.01
+            for _ in range(5):
+                net.train(xk, y, a)
+        assert np.array_equal(sync.get_arena(0), hog.get_arena(0)) and np.array_equal(sync.get_arena(1), hog.get_arena(1))
+        p1, v1 = sync.predict_p_and_v(xk)
+        p2, v2 = hog.predict_p_and_v(xk)
+        assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+        stop = time.time() + 1.5
+        counts, errors = [0, 0], []
+
+        def trainer(i):
+            try:
+                while time.time() < stop:
+                    hog.train(xk, y, a)
+                    counts[i] += 1
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+        ths = [threading.Thread(target=trainer, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(60)
+        assert not errors and min(counts) > 20
+        assert hog.get_global_step() == 5 + sum(counts)
+        assert np.all(np.isfinite(hog.get_arena(0)))
+    finally:
+        sync.close()
+        hog.close()
