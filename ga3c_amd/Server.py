@@ -103,6 +103,10 @@ class Server:
         return self.stop_step is None or self.training_step < self.stop_step
 
     def train_model(self, x_, r_, a_, x2, done, trainer_id):
+        if self.dp is None:             # trainer threads go straight to the model, as in Server.py:141-142
+            self.model.train(x_, r_, a_, x2, done, trainer_id)
+            self._count_train_step(x_.shape[0], x_, r_, a_)
+            return
         with self.dp_lock:
             if not self._may_step():
                 return
@@ -119,6 +123,10 @@ class Server:
 
     def train_model_rows(self, row_offsets, r_, a_, trainer_id):
         """train_model for rows that are still sitting in the transport (zero-copy intake)."""
+        if self.dp is None:
+            self.model.train_offsets(row_offsets, r_, a_)
+            self._count_train_step(row_offsets.shape[0], None, r_, a_)
+            return
         with self.dp_lock:
             if not self._may_step():
                 return
