@@ -1,0 +1,33 @@
+"""-m gpu: bench.py prints ONE JSON line with the fields the driver's contract names."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(300)
+def test_bench_line_contract(tmp_path):
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--cpu-seconds", "1",
+                          "--e2e-seconds", "3", "--e2e-agents", "4"], capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # exactly one line on stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "predictions_per_sec" and d["unit"] == "predictions/s" and d["n_gpus"] == 1
+    assert d["steps"] == 20 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["value"] > 1e5 and abs(d["ms_per_step"] - 128.0 / d["value"] * 1e3) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and 0.0 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "predictions/s" and c["sample"]
+    assert d["train"]["value"] > 100 and d["e2e"]["predictions_per_sec"] > 100
