@@ -1,0 +1,30 @@
+"""Latency of one predictor round trip through the C ABI at small batch (development aid)."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+import ga3c_amd, Transport as tp
+from NetworkVP import Network
+
+t = tp.Transport.create(tp.unique_name("lat"), 64, 6, 84 * 84 * 4, 8, 6)
+net = Network("gpu:0", "lat", 6, (84, 84, 4), max_batch=128, predict_lanes=2)
+net.register_transport(t)
+rng = np.random.default_rng(0)
+t.agent_states[:] = rng.integers(0, 256, size=(64, 84 * 84 * 4), dtype=np.uint8)
+for n in (1, 8, 16, 32, 64):
+    ids = np.arange(n, dtype=np.uint32)
+    offs = t.state_offsets(ids)
+    x = np.ascontiguousarray(t.agent_states[:n]).reshape(n, 84, 84, 4)
+    for _ in range(50):
+        net.predict_offsets(offs)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        net.predict_offsets(offs)
+    a = (time.perf_counter() - t0) / 500 * 1e6
+    for _ in range(50):
+        net.predict_p_and_v(x)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        net.predict_p_and_v(x)
+    b = (time.perf_counter() - t0) / 500 * 1e6
+    print("batch %3d: zero-copy gather %.1f us per call, host-buffer u8 %.1f us per call" % (n, a, b))
+net.close(); t.shutdown(); t.close()
