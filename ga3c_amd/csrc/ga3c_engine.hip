@@ -352,7 +352,7 @@ int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, cons
   return GA3C_OK;
 }
 
-int read_losses(ga3c_net* net, TrainLane& t, float* losses) {
+int read_losses(ga3c_net*, TrainLane& t, float* losses) {
   float* hl = t.h_out;
   HIPCHK(hipMemcpyAsync(hl, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
   HIPCHK(hipStreamSynchronize(t.st));
@@ -415,7 +415,6 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
   HIPCHK(hipSetDevice(net->cfg.device));
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
-  const int A = net->A;
   if (u8) {
     const size_t nb = (size_t)B * XS;
     if (is_pinned(x)) {

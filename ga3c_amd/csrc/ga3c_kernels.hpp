@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const void* __restric
   float* wl = lds + C1_RIN * C1_PW * 4;     // [j = s*4+t][lane = g*16+r] = W1[16s+4g+t][r]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x / 7, band = blockIdx.x - b * 7;
+  if (b >= B) return;                       // block-uniform guard: the grid is B * 7
   const int y_base = 4 * C1_HB * band - 2;  // image row of padded band row 0
   // band rows -> LDS (zero fill outside the image)
   f32x4 stage[6];
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restri
   float* wl = lds + C2_PW * C2_PW * C1;      // [j][lane] = W2[16s+4g+t][half*16 + r]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x >> 1, half = blockIdx.x & 1;
+  if (b >= B) return;                       // block-uniform guard: the grid is B * 2
   const float* nb = n1 + (size_t)b * N1S;
   // padded image: 24*24*4 = 2304 float4 -> 9 per thread
   f32x4 stage[9];
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   float* wl2 = wl1 + 64 * 64;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x >> 1, h = blockIdx.x & 1;
+  if (b >= B) return;                                        // block-uniform guard: the grid is B * 2
   // conv2 rows 0..4 | 5..10: then each half has <= 16 conv1 tiles and <= 16 conv2 items, one per wave
   const int c2r0 = h ? 5 : 0, c2nr = h ? 6 : 5;              // conv2 output rows of this half
   const int n1r0 = h ? 9 : 0, n1nr = h ? 12 : 11;            // n1 rows it needs (rows 9,10 are computed by both)
@@ -679,6 +682,7 @@ __device__ __forceinline__ void heads_bwd_role(const HeadBwdArgs& h, int role) {
 __device__ __forceinline__ void dense1_dw_body(const float* __restrict__ flat, const float* __restrict__ dd1,
                                                         float* __restrict__ g_wd, float* __restrict__ g_bd, int B,
                                                         HeadBwdArgs hb, int bx, int by, int gx) {
+  (void)gx;
   if (bx >= FLAT / 32) {   // block-uniform
     if (by == 0) heads_bwd_role(hb, bx - FLAT / 32);
     return;
@@ -757,6 +761,7 @@ template <int MT>
 __device__ __forceinline__ void dense1_dx_body(const float* __restrict__ dd1, const float* __restrict__ wd,
                                                const float* __restrict__ n2, float* __restrict__ dn2, int B, int bx, int by,
                                                int gx) {
+  (void)gx;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int n0 = bx * 32;
   const int m0 = (by * 4 + (threadIdx.x >> 6)) * 16 * MT;
@@ -975,6 +980,8 @@ __device__ __forceinline__ void conv2_dx_body(const float* __restrict__ dn2, con
   __shared__ __attribute__((aligned(16))) float c2dx_lds[C2DX_DN + C2DX_W];
   float* dnl = c2dx_lds;
   float* wl = c2dx_lds + C2DX_DN;
+  (void)gx;
+  if (bx >= B) return;   // block-uniform guard: bx = sample
   switch (by) {   // block-uniform: bx = sample, by = parity class
     case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, bx, dnl, wl); break;
     case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, bx, dnl, wl); break;
