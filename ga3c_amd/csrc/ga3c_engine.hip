@@ -675,6 +675,8 @@ int ga3c_net_get_arena(ga3c_net* net, int32_t which, float* out, int64_t count) 
   if (count != net->n) return fail(GA3C_EINVAL, "count %lld != arena size %lld", (long long)count, (long long)net->n);
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
+  std::vector<std::unique_lock<std::mutex>> xl;   // Hogwild: no train lane may be mid-step while the arena is copied
+  for (TrainLane* t : net->xtr) xl.emplace_back(t->mu);
   std::unique_lock<std::shared_mutex> lk(net->wmu);
   CHK(sync_all(net));
   float* src = arena_ptr(net, which);
@@ -688,6 +690,8 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
   if (count != net->n) return fail(GA3C_EINVAL, "count %lld != arena size %lld", (long long)count, (long long)net->n);
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
+  std::vector<std::unique_lock<std::mutex>> xl;
+  for (TrainLane* t : net->xtr) xl.emplace_back(t->mu);
   std::unique_lock<std::shared_mutex> lk(net->wmu);
   CHK(sync_all(net));
   float* dst = arena_ptr(net, which);
