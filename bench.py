@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--e2e-seconds", type=float, default=8.0,
                     help="also run the whole engine (agent processes -> transport -> predictor/trainer threads) this long; 0 disables")
     ap.add_argument("--e2e-agents", type=int, default=32)
+    ap.add_argument("--device-override", type=int, default=-1,
+                    help="rehearsal only: put every rank on this device (RCCL then refuses duplicate GPUs and the "
+                         "train leg is reported as null)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,6 +71,8 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    if args.device_override >= 0:
+        local_rank = args.device_override
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

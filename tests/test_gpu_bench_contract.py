@@ -31,3 +31,32 @@ def test_bench_line_contract(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "predictions/s" and c["sample"]
     assert d["train"]["value"] > 100 and d["e2e"]["predictions_per_sec"] > 100
+
+
+@pytest.mark.timeout(400)
+def test_two_rank_launch_path(tmp_path):
+    """The driver's multi-GPU launch line, rehearsed with two ranks.  On a one-GPU box both ranks are put on device 0:
+    RCCL refuses duplicate GPUs, which exercises the fallback (prediction leg measured, train leg null); with two or
+    more GPUs the real data-parallel path runs."""
+    import socket
+    import torch
+    ngpu = torch.cuda.device_count()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+           "--cpu-seconds", "0", "--e2e-seconds", "0"]
+    if ngpu < 2:
+        cmd += ["--device-override", "0"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=380, cwd=str(tmp_path))
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["value"] > 1e5
+    if ngpu < 2:
+        assert d["data_parallel_error"] and d["train"]["value"] is None
+    else:
+        assert d["data_parallel_error"] is None and d["train"]["value"] > 100
