@@ -80,3 +80,4 @@ class Config:
                                         # as the reference's trainer threads do; False: synchronous steps (default)
     ZERO_COPY = True                    # GPU gathers states straight from the registered shm transport
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often
+    NATIVE_PREDICTOR = True             # ThreadPredictor's loop in native code (ga3c_pq_serve) when ZERO_COPY is on

@@ -7,7 +7,14 @@ shifts one new 84x84 uint8 plane, k ~ U{0..255} from PCG64(RANDOM_SEED + agent i
 episodes last SYNTHETIC_EPISODE_LENGTH steps; reward is +-1 with probability 0.01 each; `done` on the
 last step.  The uint8 stack is exposed as .current_u8 / .previous_u8 so the transport can ship 28,224
 bytes per state; the f32 views are computed on demand with the reference's own arithmetic.
+
+The FIFO is kept as one little-endian uint32 per pixel (byte c = frame c, oldest first): pushing a frame is
+`(stack >> 8) | (frame << 24)`, which yields the same [84,84,4] bytes as np.stack(frames, axis=-1) in a third
+of the time, and Generator.bytes() yields the same stream as integers(0, 256, dtype=uint8)
+(tests/test_control_plane_cpu.py pins both equalities).
 """
+import sys
+
 import numpy as np
 
 from Config import Config
@@ -47,7 +54,8 @@ class Environment:
     def reset(self):
         self.total_reward = 0
         self._t = 0
-        self._frames = []
+        self._filled = 0
+        self._stack32 = np.zeros((Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH), np.uint32)
         self._push_frame()
         self.previous_u8 = self.current_u8 = None
 
@@ -64,11 +72,16 @@ class Environment:
 
     # ---- internals
     def _push_frame(self):
-        if len(self._frames) == self.nb_frames:
-            self._frames.pop(0)
-        self._frames.append(self.rng.integers(0, 256, size=(Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH), dtype=np.uint8))
+        h, w = Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH
+        frame = np.frombuffer(self.rng.bytes(h * w), np.uint8).reshape(h, w)
+        self._stack32 = (self._stack32 >> _U8) | (frame.astype(np.uint32) << _U24)
+        self._filled = min(self._filled + 1, self.nb_frames)
 
     def _stack(self):
-        if len(self._frames) < self.nb_frames:
+        if self._filled < self.nb_frames:
             return None                                   # frame queue not full yet (Environment.py:64-65)
-        return np.ascontiguousarray(np.stack(self._frames, axis=-1))     # [84,84,4] HWC (Environment.py:66-68)
+        return self._stack32.view(np.uint8).reshape(Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH, 4)   # HWC (:66-68)
+
+
+assert sys.byteorder == "little" and Config.STACKED_FRAMES == 4, "the uint32 frame FIFO assumes 4 frames, LE bytes"
+_U8, _U24 = np.uint32(8), np.uint32(24)

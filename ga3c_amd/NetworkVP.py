@@ -194,6 +194,11 @@ class Network:
         """Unpin the segment (call before the transport is unmapped)."""
         nat.check(self._lib.ga3c_net_unregister_host(self._h), "ga3c_net_unregister_host")
 
+    def gather_entry(self):
+        """(address of ga3c_net_predict_gather, engine handle, u8 flag): what the native predictor loop
+        (ga3c_pq_serve, include/ga3c_host.h) calls for every batch instead of predict_offsets()."""
+        return C.cast(self._lib.ga3c_net_predict_gather, C.c_void_p).value, self._h, int(self._transport_u8)
+
     def predict_offsets(self, offsets):
         """offsets: int64[B] byte offsets of the states inside the registered segment."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

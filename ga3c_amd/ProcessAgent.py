@@ -83,9 +83,14 @@ class ProcessAgent(MP.Process):
 
     @staticmethod
     def select_action(actions, prediction):
+        """Reference: np.random.choice(actions, p=prediction) (ProcessAgent.py:109-115).  This is that call's own
+        algorithm -- normalised float64 cdf, one uniform from the global RandomState, searchsorted(side='right') --
+        without its per-call argument validation (~30 us); same seed, same draws (tests/test_control_plane_cpu.py)."""
         if Config.PLAY_MODE:
             return int(np.argmax(prediction))
-        return int(np.random.choice(actions, p=prediction))
+        cdf = np.cumsum(prediction, dtype=np.float64)
+        cdf /= cdf[-1]
+        return int(actions[min(int(cdf.searchsorted(np.random.random_sample(), side='right')), len(cdf) - 1)])
 
     # ---- episode loop ------------------------------------------------------------------------
     def run_episode(self):

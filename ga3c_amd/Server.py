@@ -53,7 +53,7 @@ class Server:
                 print("checkpoint not loaded: %s" % e)
         self.training_step = 0
         self.frame_counter = 0
-        self.predictions_served = 0
+        self._served_by_retired = 0
         self.agents = []
         self.agent_id = 0
         self.predictors = []
@@ -83,7 +83,11 @@ class Server:
     def remove_predictor(self):
         self.predictors[-1].exit_flag = True
         self.predictors[-1].join()
-        self.predictors.pop()
+        self._served_by_retired += self.predictors.pop().served
+
+    @property
+    def predictions_served(self):
+        return self._served_by_retired + sum(p.served for p in self.predictors)
 
     def add_trainer(self):
         self.trainers.append(ThreadTrainer(self, len(self.trainers)))

@@ -5,12 +5,21 @@ PREDICTION_BATCH_SIZE WITHOUT waiting, run one forward, hand (p[i], v[i]) back t
 Differences forced by the transport: the blocking pop times out every QUEUE_TIMEOUT_MS so that
 remove_predictor() cannot hang on an idle queue (the reference's :50 can); ids are u32, and the
 network-tester id 100 special case (:64-66) is not reproduced.
+
+With the zero-copy transport and a model that offers gather_entry() the loop itself runs in native code
+(ga3c_pq_serve, include/ga3c_host.h: the same pop -> offsets -> ga3c_net_predict_gather -> respond steps), in
+time slices of SERVE_SLICE_MS so that this thread holds the interpreter lock only to look at exit_flag and fold the
+counters; Config.NATIVE_PREDICTOR = False keeps the Python loop below.
 """
+import time
 from threading import Thread
 
 import numpy as np
 
 from Config import Config
+import _native as nat
+
+SERVE_SLICE_MS = 50
 
 
 class ThreadPredictor(Thread):
@@ -24,9 +33,24 @@ class ThreadPredictor(Thread):
         self.exit_flag = False
         self.batches = 0
         self.served = 0
+        self.seconds = {"pop": 0.0, "predict": 0.0, "respond": 0.0}     # where the loop's wall time went
+        self.native = False
+
+    def _run_native(self, entry, handle, u8):
+        t, st = self.transport, nat.ServeStats()
+        self.native = True
+        while not self.exit_flag:
+            rc = t.serve(entry, handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+            self.batches, self.served = st.batches, st.served
+            self.seconds = {"pop": st.ns_pop * 1e-9, "predict": st.ns_predict * 1e-9, "respond": st.ns_respond * 1e-9}
+            if rc < 0:
+                break                                   # transport shut down
 
     def run(self):
         t = self.transport
+        entry = getattr(self.server.model, "gather_entry", None)
+        if entry and getattr(self.server, "zero_copy", False) and getattr(Config, "NATIVE_PREDICTOR", True):
+            return self._run_native(*entry())
         bmax = Config.PREDICTION_BATCH_SIZE
         ids = np.zeros(bmax, dtype=np.uint32)
         u8 = t.state_bytes == int(np.prod(self.state_dim))
@@ -37,8 +61,12 @@ class ThreadPredictor(Thread):
         if not getattr(self.server, "zero_copy", False):
             staging = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
         zero_copy = getattr(self.server, "zero_copy", False)
+        clock, spent = time.perf_counter, self.seconds
         while not self.exit_flag:
+            t0 = clock()
             size = t.pop_batch(ids, Config.QUEUE_TIMEOUT_MS)
+            t1 = clock()
+            spent["pop"] += t1 - t0
             if size == 0:
                 continue
             if size < 0:
@@ -49,7 +77,9 @@ class ThreadPredictor(Thread):
                 np.take(t.agent_states, ids[:size], axis=0, out=staging[:size])
                 batch = staging[:size] if u8 else staging[:size].view(np.float32)
                 p, v = self.server.model.predict_p_and_v(batch.reshape((size,) + tuple(self.state_dim)))
+            t2 = clock()
             t.respond(ids, size, np.ascontiguousarray(p, np.float32), np.ascontiguousarray(v, np.float32))
+            spent["predict"] += t2 - t1
+            spent["respond"] += clock() - t2
             self.batches += 1
             self.served += size
-            self.server.predictions_served += size

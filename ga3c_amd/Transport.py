@@ -84,6 +84,12 @@ class Transport:
         nat.check_host(self._lib.ga3c_pq_respond(self._h, nat.ptr(ids, nat.u32p), n, nat.ptr(p), nat.ptr(v)),
                        "ga3c_pq_respond")
 
+    def serve(self, entry, net_handle, u8, max_batch, slice_ms, stats):
+        """One time slice of the native predictor loop (ga3c_pq_serve).  `entry` is the address of a function with
+        ga3c_net_predict_gather's signature, `stats` a _native.ServeStats that keeps accumulating."""
+        rc = self._lib.ga3c_pq_serve(self._h, entry, net_handle, int(u8), int(max_batch), int(slice_ms), C.addressof(stats))
+        return nat.check_host(rc, "ga3c_pq_serve")
+
     # ---- training queue
     def rollout_views(self, slot):
         base = self._ro_off0 + slot * self._ro_stride

@@ -36,6 +36,11 @@ class ShmConfig(C.Structure):
                 ("train_slots", C.c_int32), ("train_rows", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
+class ServeStats(C.Structure):     # include/ga3c_host.h: ga3c_serve_stats
+    _fields_ = [("batches", C.c_int64), ("served", C.c_int64), ("ns_pop", C.c_int64), ("ns_predict", C.c_int64),
+                ("ns_respond", C.c_int64), ("largest_batch", C.c_int64), ("reserved", C.c_int64 * 2)]
+
+
 HIP_SIGNATURES = {
     "ga3c_last_error": (C.c_char_p, []),
     "ga3c_device_count": (C.c_int, [i32p]),
@@ -94,6 +99,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_wait": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32]),
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),
+    "ga3c_pq_serve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_tq_acquire": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_tq_states": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "ga3c_tq_returns": (C.c_void_p, [C.c_void_p, C.c_int32]),

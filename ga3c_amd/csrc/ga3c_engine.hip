@@ -168,7 +168,7 @@ bool is_pinned(const void* p) {
 
 // ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
 int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, bool train,
-                   const TrainLane* tl, float beta) {
+                   const TrainLane* tl, float beta, float* out_p = nullptr, float* out_v = nullptr) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
   const float* th = net->theta[idx];
@@ -199,7 +199,7 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   memset(&h, 0, sizeof h);
   h.part = f.part; h.ks = ks; h.B = B; h.A = A;
   h.bd = th + OFF_BD; h.wv = th + OFF_WV; h.bv = th + OFF_BV; h.wp = th + OFF_WP; h.bp = th + off_bp(A);
-  h.d1 = f.d1; h.z = f.z; h.p = f.p; h.v = f.v;
+  h.d1 = f.d1; h.z = f.z; h.p = out_p ? out_p : f.p; h.v = out_v ? out_v : f.v;   // out_*: pinned host memory, written in place
   h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
   h.log_softmax = (net->cfg.flags & GA3C_FLAG_LOG_SOFTMAX) ? 1 : 0;
   if (train) { h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.dd1 = tl->dd1; h.beta = beta; }
@@ -267,7 +267,7 @@ int launch_rmsprop(ga3c_net* net, const float* grad, float* scales, const float*
 }
 
 // forward on a prediction lane: pick the current weights under the shared lock
-int lane_forward(ga3c_net* net, Lane& L, int B) {
+int lane_forward(ga3c_net* net, Lane& L, int B, float* out_p, float* out_v) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->cur;
   {
@@ -279,7 +279,7 @@ int lane_forward(ga3c_net* net, Lane& L, int B) {
     }
   }
   HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
-  CHK(launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f));
+  CHK(launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
   return GA3C_OK;
@@ -371,12 +371,12 @@ int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
       return fail(GA3C_EINVAL, "row %d: offset %lld outside the registered segment or not 16-byte aligned", i, (long long)offsets[i]);
     h_off[i] = offsets[i];
   }
-  HIPCHK(hipMemcpyAsync(d_off, h_off, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  (void)d_off;   // the gather kernel reads the offsets out of the pinned host array itself: no H2D copy to wait for
   const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, f.xu8, B);
-  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, d_off, f.x, B);
+  if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, st, net->reg_dev, h_off, f.xu8, B);
+  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, h_off, f.x, B);
   f.x_u8 = u8;
   HIPCHK(hipGetLastError());
   return GA3C_OK;
@@ -395,12 +395,11 @@ Lane* take_lane(ga3c_net* net) {
 
 int finish_predict(ga3c_net* net, Lane* L, int B, float* p, float* v, float* z) {
   const int A = net->A;
-  CHK(lane_forward(net, *L, B));
   float* hp = L->h_out;
   float* hv = hp + (size_t)net->maxB * A;
   float* hz = hv + net->maxB;
-  HIPCHK(hipMemcpyAsync(hp, L->f.p, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
-  HIPCHK(hipMemcpyAsync(hv, L->f.v, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  // the heads kernel stores p and v straight into the lane's pinned host buffer: no D2H copies on the round trip
+  CHK(lane_forward(net, *L, B, hp, hv));
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
   HIPCHK(hipStreamSynchronize(L->st));
   memcpy(p, hp, (size_t)B * A * sizeof(float));

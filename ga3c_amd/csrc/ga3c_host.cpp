@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -46,6 +47,11 @@ int futex_wait(std::atomic<uint32_t>* addr, uint32_t expect, int timeout_ms) {
 }
 void futex_wake(std::atomic<uint32_t>* addr, int n) {
   syscall(SYS_futex, reinterpret_cast<uint32_t*>(addr), FUTEX_WAKE, n, nullptr, nullptr, 0);
+}
+int64_t now_ns() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
 }
 int64_t now_ms() {
   struct timespec ts;
@@ -465,6 +471,42 @@ int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* 
     futex_wake(&m->resp_seq, 1);
   }
   return GA3C_H_OK;
+}
+
+int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
+                  int32_t slice_ms, ga3c_serve_stats* st) {
+  if (!shm || !predict || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
+  Header* h = shm->hdr();
+  const int A = h->cfg.num_actions;
+  std::vector<uint32_t> ids((size_t)max_batch);
+  std::vector<int64_t> offs((size_t)max_batch);
+  std::vector<float> p((size_t)max_batch * A), v((size_t)max_batch);
+  const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
+  for (;;) {
+    const int64_t t0 = now_ns();
+    const int64_t left_ms = (t_end - t0 + 999999) / 1000000;
+    if (left_ms <= 0) return GA3C_H_OK;
+    const int n = ga3c_pq_pop_batch(shm, ids.data(), max_batch, (int)left_ms);
+    const int64_t t1 = now_ns();
+    st->ns_pop += t1 - t0;
+    if (n < 0) return n;
+    if (n == 0) continue;
+    for (int i = 0; i < n; ++i) {
+      if (ids[i] >= (uint32_t)h->cfg.max_agents) return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[i]);
+      offs[i] = h->agents_off + (int64_t)ids[i] * h->agent_stride;
+    }
+    const int rc = predict(net, offs.data(), n, u8, p.data(), v.data(), nullptr);
+    if (rc < 0) return fail(GA3C_H_ECALLBACK, "predict callback failed with %d on a batch of %d", rc, n);
+    const int64_t t2 = now_ns();
+    const int rr = ga3c_pq_respond(shm, ids.data(), n, p.data(), v.data());
+    if (rr < 0) return rr;
+    const int64_t t3 = now_ns();
+    st->ns_predict += t2 - t1;
+    st->ns_respond += t3 - t2;
+    st->batches += 1;
+    st->served += n;
+    if (n > st->largest_batch) st->largest_batch = n;
+  }
 }
 
 int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms) {

@@ -23,6 +23,7 @@ extern "C" {
 #define GA3C_H_ESYS (-2)      /* shm_open / mmap / ftruncate failed (errno kept) */
 #define GA3C_H_ETIMEOUT (-3)  /* a blocking call timed out (not an error for pollers) */
 #define GA3C_H_ECLOSED (-4)   /* the transport was shut down */
+#define GA3C_H_ECALLBACK (-5) /* ga3c_pq_serve: the predict callback failed (its own error string says why) */
 
 const char* ga3c_host_last_error(void);
 
@@ -78,6 +79,22 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
  * without waiting up to max_ids; returns the count (0 on timeout). */
 int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t timeout_ms);
 int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* p, const float* v);
+
+/* The whole ThreadPredictor.run loop (ThreadPredictor.py:46-66) in native code, so that a predictor thread holds no
+ * interpreter lock between batches: pop_batch -> byte offsets of the popped agents' states -> `predict` (the
+ * signature of ga3c_net_predict_gather, include/ga3c_abi.h) -> respond.  Runs for about `slice_ms`, then returns
+ * GA3C_H_OK so the caller can look at its exit flag and fold `stats` (accumulated, never reset here) into its
+ * counters; GA3C_H_ECLOSED once the segment is shut down; GA3C_H_ECALLBACK if `predict` fails (the requests
+ * of that batch are NOT answered: the caller is expected to stop the server). */
+typedef int (*ga3c_predict_rows_fn)(void* net, const int64_t* offsets, int32_t batch, int32_t u8, float* p, float* v,
+                                    float* z);
+typedef struct ga3c_serve_stats {
+  int64_t batches, served;
+  int64_t ns_pop, ns_predict, ns_respond;
+  int64_t largest_batch, reserved[2];
+} ga3c_serve_stats;
+int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
+                  int32_t slice_ms, ga3c_serve_stats* stats);
 
 /* training queue: agent side (ProcessAgent.py:175), trainer side (ThreadTrainer.py:49-59) */
 int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms);                 /* -> free slot id */

@@ -105,3 +105,44 @@ def test_convert_data_dtypes_match_reference(cfg, golden_dir):
     assert got == want
     assert x_.shape == (3, 84, 84, 4) and a_.shape == (3, 3) and np.all(a_.sum(axis=1) == 1)
     assert np.all(x_ == -1.0)                           # uint8 0 -> 0/128 - 1
+
+
+def test_select_action_draws_equal_numpy_choice(cfg):
+    from ProcessAgent import ProcessAgent
+    rng = np.random.default_rng(0)
+    actions = np.arange(6)
+    for trial in range(200):
+        z = rng.normal(size=6).astype(np.float32) * 3
+        p = np.exp(z - z.max())
+        p = (p / p.sum()).astype(np.float32)
+        np.random.seed(trial)
+        want = [int(np.random.choice(actions, p=p)) for _ in range(5)]
+        np.random.seed(trial)
+        got = [ProcessAgent.select_action(actions, p) for _ in range(5)]
+        assert got == want
+    cfg.PLAY_MODE = True
+    assert ProcessAgent.select_action(actions, np.array([0.1, 0.5, 0.2, 0.1, 0.05, 0.05], np.float32)) == 1
+
+
+def test_environment_frames_equal_stacked_integer_planes(cfg):
+    """The uint32-shift FIFO + Generator.bytes() must be the documented source: planes from
+    integers(0, 256, uint8) of PCG64(RANDOM_SEED + id), stacked oldest-first along the last axis."""
+    from Environment import Environment
+    cfg.SYNTHETIC_EPISODE_LENGTH = 6
+    env = Environment(3)
+    ref = np.random.Generator(np.random.PCG64(cfg.RANDOM_SEED + 3))
+    frames = [ref.integers(0, 256, size=(84, 84), dtype=np.uint8)]
+    assert env.current_u8 is None
+    for t in range(1, 10):
+        reward, done = env.step(0)
+        ref.random()
+        frames.append(ref.integers(0, 256, size=(84, 84), dtype=np.uint8))
+        if t < 3:
+            assert env.current_u8 is None
+            continue
+        want = np.stack(frames[-4:], axis=-1)
+        assert env.current_u8.shape == (84, 84, 4) and env.current_u8.dtype == np.uint8
+        assert np.array_equal(env.current_u8, want)
+        if t > 3:
+            assert np.array_equal(env.previous_u8, np.stack(frames[-5:-1], axis=-1))
+        assert done == (t >= 6 + 3)

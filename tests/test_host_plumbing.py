@@ -88,7 +88,6 @@ class _Server:
     def __init__(self, transport, n_act, state_dim):
         self.model = _Model(n_act)
         self.transport = transport
-        self.predictions_served = 0
         self.state_dim = state_dim
         self.calls = []
 
@@ -116,7 +115,7 @@ def test_predictor_batching_and_routing_match_reference_trace(mods, golden_dir, 
         th = ThreadPredictor(srv, 0, (sdim,), t)
         th.start()
         deadline = time.time() + 10
-        while srv.predictions_served < n_req and time.time() < deadline:
+        while th.served < n_req and time.time() < deadline:
             time.sleep(0.01)
         th.exit_flag = True
         th.join(5)
@@ -264,3 +263,83 @@ def test_environment_state_layout_and_value_set(mods):
     env.step(0)
     assert np.array_equal(env.current_u8[:, :, :3], before[:, :, 1:])      # FIFO shift of the frame stack
     assert np.array_equal(env.previous_u8, before)
+
+
+@pytest.mark.parametrize("key", ["predictor_128", "predictor_32"])
+def test_native_serve_loop_batches_and_routes_like_the_reference_trace(mods, golden_dir, key):
+    """ga3c_pq_serve (the native ThreadPredictor loop) against the same golden trace as the Python loop above; the
+    engine call is stood in for by a ctypes callback with ga3c_net_predict_gather's signature."""
+    import ctypes as C
+    nat, tp, Config = mods
+    from ThreadPredictor import ThreadPredictor
+    g = json.load(open(os.path.join(golden_dir, "batcher_traces.json")))[key]
+    n_req, sdim, n_act = g["n_requests"], g["state_dim"], 6
+    t = tp.Transport.create(tp.unique_name("t_srv"), n_req, n_act, sdim, 4, 6)
+    seen = []
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                 C.POINTER(C.c_float), C.POINTER(C.c_float))
+    def fake_predict(net, offsets, batch, u8, p, v, z):
+        seen.append(batch)
+        for i in range(batch):
+            row = t._raw[offsets[i]: offsets[i] + sdim]
+            for a in range(n_act):
+                p[i * n_act + a] = float(row[a])
+            v[i] = float(row.astype(np.float32).sum())
+        return 0
+
+    class _NativeModel:
+        def gather_entry(self):
+            return C.cast(fake_predict, C.c_void_p).value, None, 1
+
+    class _NativeServer:
+        zero_copy = True
+        model = _NativeModel()
+
+    try:
+        rng = np.random.default_rng(g["seed"])
+        states = rng.integers(0, 256, size=(n_req, sdim)).astype(np.uint8)
+        for i in range(n_req):
+            t.state_view(i)[:] = states[i]
+            t.submit(i)
+        Config.PREDICTION_BATCH_SIZE = g["batch_max"]
+        th = ThreadPredictor(_NativeServer(), 0, (sdim,), t)
+        th.start()
+        deadline = time.time() + 10
+        while th.served < n_req and time.time() < deadline:
+            time.sleep(0.01)
+        th.exit_flag = True
+        th.join(5)
+        assert th.native and not th.is_alive()
+        assert seen == g["batch_sizes"] and th.batches == len(seen) and th.served == n_req
+        for i in range(n_req):
+            rc, p, v = t.wait(i, 1000)
+            assert rc == 0
+            assert v == float(states[i].astype(np.float32).sum())
+            assert p.tolist() == states[i, :n_act].astype(np.float32).tolist()
+    finally:
+        Config.PREDICTION_BATCH_SIZE = 128
+        t.shutdown()
+        t.close()
+
+
+def test_native_serve_loop_reports_a_failing_engine(mods):
+    import ctypes as C
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_srv_err"), 4, 6, 64, 4, 6)
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                 C.POINTER(C.c_float), C.POINTER(C.c_float))
+    def failing(net, offsets, batch, u8, p, v, z):
+        return -2
+
+    try:
+        st = nat.ServeStats()
+        assert t.serve(C.cast(failing, C.c_void_p).value, None, 1, 8, 20, st) == 0      # idle slice: plain return
+        t.submit(1)
+        with pytest.raises(RuntimeError, match="predict callback failed with -2"):
+            t.serve(C.cast(failing, C.c_void_p).value, None, 1, 8, 20, st)
+        t.shutdown()
+        assert t.serve(C.cast(failing, C.c_void_p).value, None, 1, 8, 20, st) == -4    # closed
+    finally:
+        t.close()

@@ -1,0 +1,102 @@
+"""Where does whole-engine time go?  Runs the Server (synthetic agents, zero-copy transport) and samples, after a
+warm-up, the steady-state prediction / train-step rates, the mean prediction batch, and the CPU seconds burnt by
+the server process and by the agent processes (psutil), so an agent-bound run can be told from a server-bound one.
+
+    python tools/e2e_probe.py --agents 32 --predictors 2 --trainers 2 --seconds 10 [--no-train]
+
+Prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=32)
+    ap.add_argument("--predictors", type=int, default=2)
+    ap.add_argument("--trainers", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--warm", type=float, default=4.0)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--train-min-batch", type=int, default=127)
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--hogwild", action="store_true")
+    ap.add_argument("--python-predictor", action="store_true", help="keep ThreadPredictor's loop in Python")
+    args = ap.parse_args()
+
+    import psutil
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    from Server import Server
+
+    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = args.agents, args.predictors, args.trainers
+    Config.DYNAMIC_SETTINGS = False
+    Config.PREDICTION_BATCH_SIZE = args.batch
+    Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
+    Config.TRAIN_MODELS = not args.no_train
+    Config.HOGWILD = bool(args.hogwild)
+    Config.NATIVE_PREDICTOR = not args.python_predictor
+    Config.SAVE_MODELS = False
+    Config.LOAD_CHECKPOINT = False
+    Config.RESULTS_FILENAME = "/tmp/e2e_probe_results.txt"
+    Config.EPISODES = 10 ** 9
+
+    srv = Server(max_agents=args.agents)
+    me = psutil.Process()
+    snap = {}
+
+    def cpu_of(procs):
+        tot = 0.0
+        for p in procs:
+            try:
+                c = p.cpu_times()
+                tot += c.user + c.system
+            except psutil.Error:
+                pass
+        return tot
+
+    def take():
+        kids = [p for p in me.children(recursive=True)]
+        return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step,
+                "batches": sum(p.batches for p in srv.predictors),
+                "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")}, "srv_cpu": cpu_of([me]), "agent_cpu": cpu_of(kids),
+                "n_kids": len(kids)}
+
+    def sampler():
+        time.sleep(args.warm)
+        snap["a"] = take()
+        time.sleep(max(0.5, args.seconds - args.warm - 0.5))
+        snap["b"] = take()
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    srv.main(max_seconds=args.seconds)
+    th.join(timeout=5)
+    a, b = snap.get("a"), snap.get("b")
+    if not a or not b:
+        print(json.dumps({"error": "sampler did not finish"}))
+        return
+    dt = b["t"] - a["t"]
+    pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
+    print(json.dumps({
+        "agents": args.agents, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
+        "hogwild": bool(args.hogwild), "native_predictor": not args.python_predictor, "window_s": round(dt, 2), "host_cores": os.cpu_count(),
+        "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
+        "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),
+        "predictor_us_per_batch": {k: round((b["loop"][k] - a["loop"][k]) / batches * 1e6, 1) for k in b["loop"]},
+        "server_cpu_cores": round((b["srv_cpu"] - a["srv_cpu"]) / dt, 2),
+        "agent_cpu_cores": round((b["agent_cpu"] - a["agent_cpu"]) / dt, 2),
+        "agent_cpu_us_per_step": round((b["agent_cpu"] - a["agent_cpu"]) / max(1, pred) * 1e6, 1),
+        "agent_wall_us_per_step": round(dt * args.agents / max(1, pred) * 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    main()
