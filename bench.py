@@ -39,6 +39,84 @@ FLOP_CONV2_PER_SAMPLE = 1_982_464                                       # 121 * 
 MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
 
 
+def run_engine(model, seconds, agents, B, A):
+    """The whole engine for `seconds`: synthetic agents -> shm transport -> ThreadPredictor / ThreadTrainer -> `model`
+    (None = the HIP Network).  Returns rates over the steady window of the run."""
+    import threading
+    from Config import Config
+    from Server import Server
+    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = agents, 2, 2
+    Config.TRAINING_MIN_BATCH_SIZE = B - 1
+    Config.DYNAMIC_SETTINGS, Config.SAVE_MODELS, Config.TENSORBOARD = False, False, False
+    Config.PRINT_STATS_FREQUENCY = 10 ** 9
+    Config.RESULTS_FILENAME = os.devnull
+    Config.NUM_ACTIONS = A
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        srv = Server(model=model, max_agents=agents)
+        marks, native = [], []
+
+        def sampler():      # steady window: from 40% of the run (agents forked, queues warm) to just before the stop
+            for at in (0.4 * seconds, seconds - 0.3):
+                time.sleep(max(0.0, at - (time.perf_counter() - t0)))
+                marks.append((time.perf_counter(), srv.predictions_served, srv.training_step, srv.frame_counter,
+                              sum(p.batches for p in srv.predictors)))
+                native.append(any(p.native for p in srv.predictors))
+
+        t0 = time.perf_counter()
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        srv.main(max_seconds=seconds)
+        dt = time.perf_counter() - t0
+        th.join(timeout=5)
+        whole = {"predictions_per_sec": srv.predictions_served / dt, "training_steps_per_sec": srv.training_step / dt,
+                 "seconds": dt}
+        if len(marks) == 2 and marks[1][0] > marks[0][0]:
+            (ta, pa, sa, fa, ba), (tb, pb, sb, fb, bb) = marks
+            w = tb - ta
+            steady = {"predictions_per_sec": (pb - pa) / w, "training_steps_per_sec": (sb - sa) / w, "seconds": w,
+                      "train_rows_per_step": (fb - fa) / max(sb - sa, 1), "mean_predict_batch": (pb - pa) / max(bb - ba, 1)}
+        else:
+            steady = dict(whole, train_rows_per_step=srv.frame_counter / max(srv.training_step, 1), mean_predict_batch=None)
+        res = dict(steady, agents=agents, predictors=2, trainers=2, whole_run=whole,
+                   native_predictor_loop=bool(native and native[0]))
+        if model is None:
+            srv.model.close()
+        return res
+    finally:
+        sys.stdout = real_stdout
+
+
+class CPortModel:
+    """oracle/ga3c_oracle_c.c behind the Network surface the Server drives (cpu_baseline leg only)."""
+
+    def __init__(self, oc, theta, A):
+        self.oc, self.theta, self.ms, self.A = oc, theta.copy(), np.ones_like(theta), A
+        self.learning_rate, self.beta = 3e-4, 0.01
+        self.lock = __import__("threading").Lock()
+
+    @staticmethod
+    def _f32(x):
+        return x.astype(np.float32) / np.float32(128.0) - np.float32(1.0) if x.dtype == np.uint8 else x
+
+    def predict_p_and_v(self, x):
+        return list(self.oc.predict(self.theta, self.A, self._f32(x).reshape(x.shape[0], -1)))
+
+    def train(self, x, y_r, a, x2=None, done=None, trainer_id=0):
+        with self.lock:
+            self.oc.train(self.theta, self.ms, self.A, self._f32(x).reshape(x.shape[0], -1), y_r, a, self.learning_rate, self.beta)
+
+    def get_global_step(self):
+        return 0
+
+    def log(self, *a, **k):
+        pass
+
+    def save(self, episode):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +307,7 @@ def main():
                                          "OpenMP over %d threads of %d host cores" % (n, B, dt, oc.threads(), os.cpu_count()),
                                "train_steps_per_sec": m / dt2}
 
+    cpu_theta = net.get_arena(0) if "cpu_baseline" in out else None
     net.close()
 
     # ---- Hogwild trainers: the reference's default NT = 2 trainer threads update shared weights unlocked (Server.py:132-134)
@@ -249,28 +328,17 @@ def main():
 
     # ---- whole engine, BASELINE configs[1]/[2] shape: agents -> shm transport -> ThreadPredictor / ThreadTrainer -> HIP
     if rank == 0 and world == 1 and args.e2e_seconds > 0:
-        from Server import Server
-        Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = args.e2e_agents, 2, 2
-        Config.TRAINING_MIN_BATCH_SIZE = B - 1
-        Config.DYNAMIC_SETTINGS, Config.SAVE_MODELS, Config.TENSORBOARD = False, False, False
-        Config.PRINT_STATS_FREQUENCY = 10 ** 9
-        Config.RESULTS_FILENAME = os.devnull
-        Config.NUM_ACTIONS = A
-        real_stdout = sys.stdout
-        sys.stdout = sys.stderr
-        try:
-            srv = Server(max_agents=args.e2e_agents)
-            t0 = time.perf_counter()
-            srv.main(max_seconds=args.e2e_seconds)
-            dt = time.perf_counter() - t0
-            out["e2e"] = {"predictions_per_sec": srv.predictions_served / dt, "training_steps_per_sec": srv.training_step / dt,
-                          "seconds": dt, "agents": args.e2e_agents, "predictors": 2, "trainers": 2,
-                          "train_rows_per_step": srv.frame_counter / max(srv.training_step, 1),
-                          "note": "synthetic Python agents (PCG64 frames) on this box's host cores; counts predictions "
-                                  "served and train steps taken by the engine, start-up included"}
-            srv.model.close()
-        finally:
-            sys.stdout = real_stdout
+        out["e2e"] = dict(run_engine(None, args.e2e_seconds, args.e2e_agents, B, A),
+                          note="synthetic Python agents (PCG64 frames) on this box's host cores; predictions served and "
+                               "train steps taken by the engine over the steady window of the run (whole_run includes "
+                               "forking the agents)")
+        if cpu_theta is not None:      # the same harness with the oracle's C port as the model: the CPU path beside it
+            import ga3c_oracle_cport as oc
+            oc.lib().ga3c_oc_set_threads(4)       # 2 predictor + 2 trainer threads call in concurrently: 4 x 4 = the 16-core share
+            out["cpu_baseline"]["e2e"] = dict(
+                run_engine(CPortModel(oc, cpu_theta, A), args.e2e_seconds, args.e2e_agents, B, A),
+                note="same agents / transport / batcher threads, model = oracle/ga3c_oracle_c.c (host-buffer path, 4 OpenMP "
+                     "threads per calling thread)")
 
     if world > 1:
         dist.barrier()
