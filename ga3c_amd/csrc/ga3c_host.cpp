@@ -17,9 +17,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <new>
 #include <string>
 #include <vector>
+
+#include "ga3c_resample.hpp"
 
 namespace {
 
@@ -260,6 +263,68 @@ int ga3c_returns_nstep(const double* rewards, int32_t T, double gamma, double bo
     r = r < rmin ? rmin : (r > rmax ? rmax : r);
     reward_sum = gamma * reward_sum + r;
     out[t] = reward_sum;
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_frame_preprocess(const uint8_t* rgb, int32_t height, int32_t width, int32_t channels, int32_t out_h,
+                          int32_t out_w, uint8_t* plane) {
+  if (!rgb || !plane || height < 1 || width < 1 || channels < 3 || out_h < 1 || out_w < 1)
+    return fail(GA3C_H_EINVAL, "bad argument");
+  const size_t npx = (size_t)height * width;
+  std::vector<double> gray(npx);
+  double cmin = 0.0, cmax = 0.0;
+  for (size_t i = 0; i < npx; ++i) {
+    const uint8_t* px = rgb + i * channels;
+    // np.dot's order on a [H, W, 3] frame: fused multiply-adds, left to right (oracle/frame_frontend.py: rgb2gray)
+    const double g = std::fma((double)px[2], 0.114, std::fma((double)px[1], 0.587, (double)px[0] * 0.299));
+    gray[i] = g;
+    if (i == 0 || g < cmin) cmin = g;
+    if (i == 0 || g > cmax) cmax = g;
+  }
+  double cscale = cmax - cmin;
+  if (cscale == 0.0) cscale = 1.0;
+  const double scale = 255.0 / cscale;
+  std::vector<uint8_t> img(npx);
+  for (size_t i = 0; i < npx; ++i) {
+    volatile double t = gray[i] - cmin;   // separately rounded subtract and multiply, as numpy evaluates them
+    t = t * scale;
+    double c = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
+    img[i] = (uint8_t)(c + 0.5);
+  }
+  const int half = 1 << (ga3c::RESAMPLE_PRECISION_BITS - 1);
+  auto clip8 = [](int32_t acc) {
+    const int32_t v = acc >> ga3c::RESAMPLE_PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  };
+  std::vector<uint8_t> tmp;
+  const uint8_t* src = img.data();
+  int cur_w = width;
+  if (width != out_w) {   // horizontal pass
+    const ga3c::ResampleTable t = ga3c::make_bilinear_table(width, out_w);
+    tmp.resize((size_t)height * out_w);
+    for (int y = 0; y < height; ++y)
+      for (int xx = 0; xx < out_w; ++xx) {
+        const int xmin = t.bounds[(size_t)xx * 2], n = t.bounds[(size_t)xx * 2 + 1];
+        int32_t acc = half;
+        for (int x = 0; x < n; ++x) acc += (int32_t)src[(size_t)y * width + xmin + x] * t.kk[(size_t)xx * t.ksize + x];
+        tmp[(size_t)y * out_w + xx] = clip8(acc);
+      }
+    src = tmp.data();
+    cur_w = out_w;
+  }
+  if (height != out_h) {  // vertical pass
+    const ga3c::ResampleTable t = ga3c::make_bilinear_table(height, out_h);
+    for (int yy = 0; yy < out_h; ++yy) {
+      const int ymin = t.bounds[(size_t)yy * 2], n = t.bounds[(size_t)yy * 2 + 1];
+      for (int x = 0; x < cur_w; ++x) {
+        int32_t acc = half;
+        for (int k = 0; k < n; ++k) acc += (int32_t)src[(size_t)(ymin + k) * cur_w + x] * t.kk[(size_t)yy * t.ksize + k];
+        plane[(size_t)yy * cur_w + x] = clip8(acc);
+      }
+    }
+  } else {
+    memcpy(plane, src, (size_t)out_h * cur_w);
   }
   return GA3C_H_OK;
 }

@@ -38,6 +38,17 @@ int ga3c_returns_fork(const double* rewards, int32_t T, double gamma, double ter
 int ga3c_returns_nstep(const double* rewards, int32_t T, double gamma, double bootstrap_value,
                        double rmin, double rmax, double* out);
 
+/* ---- frame front-end (host side) -------------------------------------------------------------
+ * Environment._rgb2gray + _preprocess (Environment.py:52-60) up to the uint8 plane the frame queue holds:
+ *   gray  = f64 dot(rgb[..., :3], [.299, .587, .114])
+ *   u8    = scipy.misc.bytescale(gray): stretch by the frame's own min / max to 0..255, +0.5, truncate
+ *   plane = Pillow Image.resize((out_w, out_h), BILINEAR) of that 8-bit image
+ * (the reference then maps k -> k/128 - 1 in f32; the transport keeps the byte).  rgb is [height][width][channels]
+ * uint8 with channels >= 3; plane is [out_h][out_w].  Bit-exact with oracle/frame_frontend.py and with the HIP
+ * implementation behind ga3c_net_frames_* (include/ga3c_abi.h). */
+int ga3c_frame_preprocess(const uint8_t* rgb, int32_t height, int32_t width, int32_t channels, int32_t out_h,
+                          int32_t out_w, uint8_t* plane);
+
 /* ---- shared-memory transport ----------------------------------------------------------------
  * One POSIX shm segment holds
  *   agent slots   [max_agents] x { state (state_bytes), p[f32 x num_actions], v, request/response words }

@@ -9,7 +9,12 @@ What is produced, and from what:
                         itself needs gym/skimage, which are absent and stay absent, so it is not
                         imported here;
   nn_small.npz          f64-oracle outputs on seeded inputs (the NN path has no reference fixture:
-                        "parity unpinned", see oracle/ga3c_oracle.py).
+                        "parity unpinned", see oracle/ga3c_oracle.py);
+  frontend.npz          RGB frames and the uint8 84x84 planes Environment._preprocess (Environment.py:52-60) makes
+                        of them, computed with the reference's own ingredients where this image has them:
+                        numpy.dot for the gray product and Pillow's Image.resize(BILINEAR) -- the resampler
+                        scipy.misc.imresize called; scipy.misc.bytescale (SciPy <= 1.2, absent) is the one step
+                        taken from the restatement in oracle/frame_frontend.py.
 Fixtures are data only: inputs and expected outputs.
 """
 import json
@@ -177,7 +182,39 @@ def nn_small():
     np.savez_compressed(os.path.join(HERE, "nn_small.npz"), **out)
 
 
+def frontend():
+    from PIL import Image
+    import frame_frontend as ff
+    rng = np.random.default_rng(2024)
+    frames = {}
+    pong = np.empty((210, 160, 3), np.uint8)
+    pong[:] = (144, 72, 17)                                  # playfield
+    pong[:34] = (109, 118, 43)                               # score band
+    pong[24:34] = (236, 236, 236)
+    pong[194:] = (236, 236, 236)
+    pong[90:106, 16:20] = (213, 130, 74)                     # paddles and ball
+    pong[120:136, 140:144] = (92, 186, 92)
+    pong[101:105, 79:81] = (236, 236, 236)
+    pong[4:20, 36:44] = (213, 130, 74)
+    frames["pong_like"] = pong
+    frames["random"] = rng.integers(0, 256, size=(210, 160, 3), dtype=np.uint8)
+    tall = (np.add.outer(np.arange(250) * 3, np.arange(160) * 5)[..., None] // np.array([1, 2, 3]) % 256).astype(np.uint8)
+    frames["tall_gradient"] = tall
+    frames["constant"] = np.full((210, 160, 3), 77, np.uint8)
+    frames["small_random"] = rng.integers(0, 256, size=(40, 50, 3), dtype=np.uint8)
+    frames["low_contrast"] = (100 + rng.integers(0, 3, size=(210, 160, 3))).astype(np.uint8)
+    out = {}
+    for name, rgb in frames.items():
+        gray = np.dot(rgb[..., :3], [0.299, 0.587, 0.114])                       # Environment.py:54, verbatim call
+        img = Image.frombytes('L', (gray.shape[1], gray.shape[0]), ff.bytescale(gray).tobytes())   # toimage()
+        plane = np.asarray(img.resize((84, 84), resample=Image.BILINEAR))       # imresize(..., 'bilinear')
+        out["rgb_" + name] = rgb
+        out["plane_" + name] = plane.astype(np.uint8)
+    np.savez_compressed(os.path.join(HERE, "frontend.npz"), **out)
+
+
 if __name__ == "__main__":
+    frontend()
     returns_fork()
     nn_small()
     batcher_traces()
