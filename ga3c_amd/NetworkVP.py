@@ -194,6 +194,53 @@ class Network:
         """Unpin the segment (call before the transport is unmapped)."""
         nat.check(self._lib.ga3c_net_unregister_host(self._h), "ga3c_net_unregister_host")
 
+    # ---- frame front-end on the device (Environment.py:52-74; include/ga3c_abi.h: ga3c_net_frames_*) ------------
+    def frames_config(self, max_agents, height=210, width=160, channels=3):
+        nat.check(self._lib.ga3c_net_frames_config(self._h, max_agents, height, width, channels), "ga3c_net_frames_config")
+        self._frame_shape = (height, width, channels)
+
+    def _frames_arg(self, rgb):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        if rgb.ndim == 3:
+            rgb = rgb[None]
+        if rgb.shape[1:] != self._frame_shape:
+            raise ValueError("frames of shape %s, configured for %s" % (rgb.shape[1:], self._frame_shape))
+        return rgb
+
+    def preprocess_frames(self, rgb):
+        """Environment._preprocess of n RGB frames up to the uint8 plane: [n,H,W,C] -> [n,84,84] uint8."""
+        rgb = self._frames_arg(rgb)
+        planes = np.empty((rgb.shape[0], Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH), np.uint8)
+        nat.check(self._lib.ga3c_net_frames_preprocess(self._h, nat.ptr(rgb, nat.u8p), rgb.shape[0], nat.ptr(planes, nat.u8p)),
+                  "ga3c_net_frames_preprocess")
+        return planes
+
+    def push_frames(self, rgb, agents, reset=None):
+        """_update_frame_q for n distinct agents; reset[i] clears agent i's queue first (Environment.reset)."""
+        rgb = self._frames_arg(rgb)
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        rs = None if reset is None else np.ascontiguousarray(reset, dtype=np.uint8)
+        if agents.size != rgb.shape[0] or (rs is not None and rs.size != agents.size):
+            raise ValueError("one agent id (and reset flag) per frame")
+        nat.check(self._lib.ga3c_net_frames_push(self._h, nat.ptr(rgb, nat.u8p), nat.ptr(agents, nat.i32p),
+                                                 None if rs is None else nat.ptr(rs, nat.u8p), agents.size), "ga3c_net_frames_push")
+
+    def frame_state(self, agent):
+        """(uint8 [84,84,4] state or None while the queue holds fewer than 4 planes, queue depth) -- _get_current_state."""
+        state = np.empty((Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH, Config.STACKED_FRAMES), np.uint8)
+        depth = C.c_int32()
+        nat.check(self._lib.ga3c_net_frames_state(self._h, int(agent), nat.ptr(state, nat.u8p), C.byref(depth)),
+                  "ga3c_net_frames_state")
+        return (state if depth.value >= Config.STACKED_FRAMES else None), depth.value
+
+    def predict_frames(self, agents):
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        p = np.empty((agents.size, self.num_actions), dtype=np.float32)
+        v = np.empty((agents.size,), dtype=np.float32)
+        nat.check(self._lib.ga3c_net_predict_frames(self._h, nat.ptr(agents, nat.i32p), agents.size, nat.ptr(p), nat.ptr(v), None),
+                  "ga3c_net_predict_frames")
+        return [p, v]
+
     def gather_entry(self):
         """(address of ga3c_net_predict_gather, engine handle, u8 flag): what the native predictor loop
         (ga3c_pq_serve, include/ga3c_host.h) calls for every batch instead of predict_offsets()."""

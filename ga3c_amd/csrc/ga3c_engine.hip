@@ -24,6 +24,8 @@
 
 #include "../../include/ga3c_abi.h"
 #include "ga3c_kernels.hpp"
+#include "ga3c_frontend.hpp"
+#include "ga3c_resample.hpp"
 
 using namespace ga3c;
 
@@ -96,6 +98,26 @@ struct TrainLane {
 int dense_ks(int B) { return B <= 256 ? 22 : (B <= 1024 ? 11 : 2); }
 }  // namespace
 
+// Frame front-end state (ga3c_net_frames_*): resample tables, one 4-deep frame queue per agent, staging.
+struct Frames {
+  bool on = false;
+  int maxA = 0, H = 0, W = 0, C = 0, hks = 0, vks = 0;
+  size_t frame_bytes = 0, lds = 0;
+  bool cache = false;
+  int32_t* d_tab = nullptr;            // hb | hk | vb | vk
+  const int32_t *hb = nullptr, *hk = nullptr, *vb = nullptr, *vk = nullptr;
+  uint32_t* stacks = nullptr;          // [maxA][84*84] words = [84,84,4] uint8 HWC states
+  uint8_t* d_rgb = nullptr;            // [maxA] resident frames (ga3c_net_frames_upload / timing)
+  uint8_t* h_rgb = nullptr;            // pinned staging for pageable callers (read by the kernel in place)
+  uint8_t* d_planes = nullptr;
+  uint8_t* h_planes = nullptr;         // pinned
+  int32_t* h_agents = nullptr;         // pinned, read by the kernel in place
+  uint8_t* h_reset = nullptr;          // pinned
+  std::vector<int> filled;             // host mirror of each queue's depth (0..4)
+  hipStream_t st = nullptr;
+  std::mutex mu;
+};
+
 struct ga3c_net {
   ga3c_net_config cfg;
   int A = 0;
@@ -122,6 +144,7 @@ struct ga3c_net {
   void* reg_host = nullptr;            // HIP-registered host segment (the shm transport) ...
   uint8_t* reg_dev = nullptr;          // ... and the device-side address of its first byte
   int64_t reg_bytes = 0;
+  Frames fr;
   TensorTable tt;
 };
 
@@ -378,6 +401,53 @@ int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
   if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, st, net->reg_dev, h_off, f.xu8, B);
   else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, h_off, f.x, B);
   f.x_u8 = u8;
+  HIPCHK(hipGetLastError());
+  return GA3C_OK;
+}
+
+void free_frames(Frames& f) {
+  if (f.d_tab) (void)hipFree(f.d_tab);
+  if (f.stacks) (void)hipFree(f.stacks);
+  if (f.d_rgb) (void)hipFree(f.d_rgb);
+  if (f.d_planes) (void)hipFree(f.d_planes);
+  if (f.h_rgb) (void)hipHostFree(f.h_rgb);
+  if (f.h_planes) (void)hipHostFree(f.h_planes);
+  if (f.h_agents) (void)hipHostFree(f.h_agents);
+  if (f.h_reset) (void)hipHostFree(f.h_reset);
+  if (f.st) (void)hipStreamDestroy(f.st);
+  f.d_tab = nullptr; f.stacks = nullptr; f.d_rgb = f.h_rgb = f.d_planes = f.h_planes = f.h_reset = nullptr;
+  f.h_agents = nullptr; f.st = nullptr; f.on = false;
+}
+
+// Device-visible address of `bytes` caller bytes at p: inside the registered transport segment, pinned host memory
+// and device memory are used where they lie; pageable memory returns nullptr (the caller stages it).
+const uint8_t* device_visible(ga3c_net* net, const void* p, size_t bytes) {
+  const uint8_t* q = static_cast<const uint8_t*>(p);
+  if (net->reg_host) {
+    const uint8_t* b = static_cast<const uint8_t*>(net->reg_host);
+    if (q >= b && q + bytes <= b + net->reg_bytes) return net->reg_dev + (q - b);
+  }
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice) return static_cast<const uint8_t*>(at.devicePointer);
+  return nullptr;
+}
+
+// one launch of the front-end over n frames; agents/reset/planes may be null (see FrameArgs)
+int launch_frames(ga3c_net* net, const uint8_t* rgb_dev, const int32_t* agents, const uint8_t* reset, uint8_t* planes,
+                  int n) {
+  Frames& f = net->fr;
+  FrameArgs a;
+  a.rgb = rgb_dev; a.agents = agents; a.reset = reset; a.planes = planes; a.stacks = f.stacks;
+  a.hb = f.hb; a.hk = f.hk; a.vb = f.vb; a.vk = f.vk;
+  a.H = f.H; a.W = f.W; a.C = f.C; a.OH = IMG; a.OW = IMG; a.hks = f.hks; a.vks = f.vks;
+  const bool cache = f.cache && (reinterpret_cast<uintptr_t>(rgb_dev) & 3) == 0;
+  const size_t lds = frontend_lds_bytes(f.H, f.W, f.C, IMG, IMG, f.hks, f.vks, cache);
+  if (cache) hipLaunchKernelGGL(frame_frontend_kernel<true>, dim3(n), dim3(FE_THREADS), lds, f.st, a);
+  else hipLaunchKernelGGL(frame_frontend_kernel<false>, dim3(n), dim3(FE_THREADS), lds, f.st, a);
   HIPCHK(hipGetLastError());
   return GA3C_OK;
 }
@@ -641,6 +711,7 @@ int ga3c_net_destroy(ga3c_net* net) {
     free_train_lane(*t);
     delete t;
   }
+  free_frames(net->fr);
   if (net->reg_host) (void)hipHostUnregister(net->reg_host);
   for (int i = 0; i < 2; ++i) {
     if (net->theta[i]) (void)hipFree(net->theta[i]);
@@ -819,6 +890,169 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   CHK(train_grads(net, t, batch, beta));
   CHK(train_apply(net, t, learning_rate));
   return read_losses(net, t, losses);
+}
+
+// ---- frame front-end ------------------------------------------------------------------------------------------
+int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  if (max_agents < 1 || height < 1 || width < 1 || (channels != 3 && channels != 4))
+    return fail(GA3C_EINVAL, "frames: need max_agents >= 1, a positive frame size and 3 or 4 channels");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  Frames& f = net->fr;
+  std::lock_guard<std::mutex> g(f.mu);
+  free_frames(f);
+  const ResampleTable th = make_bilinear_table(width, IMG), tv = make_bilinear_table(height, IMG);
+  f.maxA = max_agents; f.H = height; f.W = width; f.C = channels; f.hks = th.ksize; f.vks = tv.ksize;
+  f.frame_bytes = (size_t)height * width * channels;
+  const size_t lds_cache = frontend_lds_bytes(height, width, channels, IMG, IMG, f.hks, f.vks, true);
+  f.cache = f.frame_bytes % 4 == 0 && lds_cache <= 158 * 1024;
+  f.lds = frontend_lds_bytes(height, width, channels, IMG, IMG, f.hks, f.vks, f.cache);
+  if (f.lds > 158 * 1024) return fail(GA3C_EINVAL, "frames: a %dx%d frame does not fit the kernel's LDS plan", height, width);
+  for (const void* fn : {reinterpret_cast<const void*>(&frame_frontend_kernel<true>),
+                         reinterpret_cast<const void*>(&frame_frontend_kernel<false>)})
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));
+  std::vector<int32_t> tab;
+  tab.insert(tab.end(), th.bounds.begin(), th.bounds.end());
+  tab.insert(tab.end(), th.kk.begin(), th.kk.end());
+  tab.insert(tab.end(), tv.bounds.begin(), tv.bounds.end());
+  tab.insert(tab.end(), tv.kk.begin(), tv.kk.end());
+  HIPCHK(hipMalloc((void**)&f.d_tab, tab.size() * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(f.d_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  f.hb = f.d_tab; f.hk = f.hb + th.bounds.size(); f.vb = f.hk + th.kk.size(); f.vk = f.vb + tv.bounds.size();
+  const size_t words = (size_t)max_agents * IMG * IMG;
+  HIPCHK(hipMalloc((void**)&f.stacks, words * sizeof(uint32_t)));
+  HIPCHK(hipMemset(f.stacks, 0, words * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&f.d_rgb, (size_t)max_agents * f.frame_bytes));
+  HIPCHK(hipMalloc((void**)&f.d_planes, (size_t)max_agents * IMG * IMG));
+  HIPCHK(hipHostMalloc((void**)&f.h_rgb, (size_t)max_agents * f.frame_bytes, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&f.h_planes, (size_t)max_agents * IMG * IMG, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&f.h_agents, (size_t)max_agents * sizeof(int32_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&f.h_reset, (size_t)max_agents, hipHostMallocDefault));
+  HIPCHK(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
+  f.filled.assign((size_t)max_agents, 0);
+  f.on = true;
+  return GA3C_OK;
+}
+
+// rgb as the kernel can read it: in place when device-visible, else through the pinned staging buffer
+static const uint8_t* frames_source(ga3c_net* net, const uint8_t* rgb, int n) {
+  Frames& f = net->fr;
+  const size_t bytes = (size_t)n * f.frame_bytes;
+  const uint8_t* dev = device_visible(net, rgb, bytes);
+  if (dev) return dev;
+  memcpy(f.h_rgb, rgb, bytes);
+  return f.h_rgb;
+}
+
+int ga3c_net_frames_preprocess(ga3c_net* net, const uint8_t* rgb, int32_t n, uint8_t* planes) {
+  if (!net || !rgb || !planes) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (n < 1 || n > f.maxA) return fail(GA3C_EINVAL, "frames: %d frames outside [1,%d]", n, f.maxA);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  CHK(launch_frames(net, frames_source(net, rgb, n), nullptr, nullptr, f.h_planes, n));   // planes land in pinned memory
+  HIPCHK(hipStreamSynchronize(f.st));
+  memcpy(planes, f.h_planes, (size_t)n * IMG * IMG);
+  return GA3C_OK;
+}
+
+int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agents, const uint8_t* reset, int32_t n) {
+  if (!net || !rgb || !agents) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (n < 1 || n > f.maxA) return fail(GA3C_EINVAL, "frames: %d frames outside [1,%d]", n, f.maxA);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  std::vector<uint8_t> seen((size_t)f.maxA, 0);
+  for (int i = 0; i < n; ++i) {
+    if (agents[i] < 0 || agents[i] >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agents[i], f.maxA);
+    if (seen[agents[i]]) return fail(GA3C_EINVAL, "frames: agent %d appears twice in one push", agents[i]);
+    seen[agents[i]] = 1;
+    f.h_agents[i] = agents[i];
+    f.h_reset[i] = reset ? reset[i] : 0;
+  }
+  CHK(launch_frames(net, frames_source(net, rgb, n), f.h_agents, f.h_reset, nullptr, n));
+  HIPCHK(hipStreamSynchronize(f.st));
+  for (int i = 0; i < n; ++i) {
+    int& d = f.filled[agents[i]];
+    d = (reset && reset[i]) ? 1 : (d < CIN ? d + 1 : CIN);
+  }
+  return GA3C_OK;
+}
+
+int ga3c_net_frames_state(ga3c_net* net, int32_t agent, uint8_t* state, int32_t* filled) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (agent < 0 || agent >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agent, f.maxA);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  if (filled) *filled = f.filled[agent];
+  if (state) HIPCHK(hipMemcpy(state, f.stacks + (size_t)agent * IMG * IMG, XS, hipMemcpyDeviceToHost));
+  return GA3C_OK;
+}
+
+int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, float* p, float* v, float* z) {
+  if (!net || !agents || !p || !v) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (n < 1 || n > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", n, net->maxB);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  {
+    std::lock_guard<std::mutex> g(f.mu);
+    for (int i = 0; i < n; ++i) {
+      if (agents[i] < 0 || agents[i] >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agents[i], f.maxA);
+      if (f.filled[agents[i]] < CIN)
+        return fail(GA3C_ESTATE, "frames: agent %d has %d of %d frames queued (Environment.py:64-65: no state yet)",
+                    agents[i], f.filled[agents[i]], CIN);
+    }
+  }
+  Lane* L = take_lane(net);
+  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  for (int i = 0; i < n; ++i) L->h_off[i] = (int64_t)agents[i] * XS;
+  const int64_t total = (int64_t)n * (XS / 16);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, L->st, reinterpret_cast<const uint8_t*>(f.stacks),
+                     L->h_off, L->f.xu8, n);
+  HIPCHK(hipGetLastError());
+  L->f.x_u8 = true;
+  return finish_predict(net, L, n, p, v, z);
+}
+
+int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n) {
+  if (!net || !rgb) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (n < 1 || n > f.maxA) return fail(GA3C_EINVAL, "frames: %d frames outside [1,%d]", n, f.maxA);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  HIPCHK(hipMemcpy(f.d_rgb, rgb, (size_t)n * f.frame_bytes, hipMemcpyHostToDevice));
+  return GA3C_OK;
+}
+
+int ga3c_net_time_frames(ga3c_net* net, int32_t n, int32_t iters, float* elapsed_ms) {
+  if (!net || !elapsed_ms) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (n < 1 || n > f.maxA || iters < 1) return fail(GA3C_EINVAL, "frames: bad n / iters");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  for (int i = 0; i < n; ++i) { f.h_agents[i] = i; f.h_reset[i] = 0; }
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  CHK(launch_frames(net, f.d_rgb, f.h_agents, f.h_reset, nullptr, n));   // warm
+  HIPCHK(hipEventRecord(e0, f.st));
+  for (int it = 0; it < iters; ++it) CHK(launch_frames(net, f.d_rgb, f.h_agents, f.h_reset, nullptr, n));
+  HIPCHK(hipEventRecord(e1, f.st));
+  HIPCHK(hipEventSynchronize(e1));
+  HIPCHK(hipEventElapsedTime(elapsed_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (int i = 0; i < n; ++i) f.filled[i] = CIN;   // iters + 1 >= ... pushes went into queues 0..n-1
+  return GA3C_OK;
 }
 
 int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch) {

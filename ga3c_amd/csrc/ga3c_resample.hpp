@@ -23,6 +23,9 @@ struct ResampleTable {
 };
 
 inline ResampleTable make_bilinear_table(int in_size, int out_size) {
+#ifdef __clang__
+#pragma clang fp contract(off)   // every product and sum rounded separately, as Pillow's C and the oracle do
+#endif
   ResampleTable t;
   t.in_size = in_size;
   t.out_size = out_size;

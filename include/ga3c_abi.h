@@ -134,6 +134,27 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
 int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses);
 
+/* Frame front-end on the device: Environment._rgb2gray + _preprocess
+ * (ga3c/Environment.py:52-60) and the 4-deep frame queue of :62-74, so that an actor ships only the emulator's raw
+ * RGB frame and the [84,84,4] state never leaves HBM.  The arithmetic is the reference's, bit for bit (see
+ * include/ga3c_host.h: ga3c_frame_preprocess, and oracle/frame_frontend.py): f64 gray, per-frame min/max bytescale,
+ * Pillow's BILINEAR resize to 84x84.
+ *   frames_config     height x width x channels (3 or 4) of the frames to come; one queue per agent in [0,max_agents)
+ *   frames_preprocess stateless: n frames -> n uint8 planes [84*84]                 (= Environment._preprocess)
+ *   frames_push       n frames into the queues of n DISTINCT agents; reset[i] != 0 clears that queue first
+ *                     (Environment.reset, :86-90)                                    (= _update_frame_q)
+ *   frames_state      one agent's uint8 [84,84,4] state and queue depth; depth < 4 means "no state yet" (:64-65)
+ *   predict_frames    forward pass on the queued states of `agents` (every queue must be full)
+ * rgb may be pageable, pinned, device memory or lie in the registered transport segment (read in place then). */
+int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels);
+int ga3c_net_frames_preprocess(ga3c_net* net, const uint8_t* rgb, int32_t n, uint8_t* planes);
+int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agents, const uint8_t* reset, int32_t n);
+int ga3c_net_frames_state(ga3c_net* net, int32_t agent, uint8_t* state, int32_t* filled);
+int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, float* p, float* v, float* z);
+/* bench helpers: n frames resident in HBM, then `iters` pushes of them timed with events on the frames stream */
+int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n);
+int ga3c_net_time_frames(ga3c_net* net, int32_t n, int32_t iters, float* elapsed_ms);
+
 /* Pinned host memory for staging arrays (ThreadPredictor.py:46-47 `states`), so that
  * predict/train copy by DMA without an intermediate host copy. */
 int ga3c_host_alloc(void** ptr, int64_t bytes);

@@ -1,0 +1,139 @@
+"""-m gpu: the device-side frame front-end (ga3c_net_frames_*, through the C ABI) against oracle/frame_frontend.py and
+the golden planes.  Everything here is byte work: the bar is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import frame_frontend as ff
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def net():
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    n = Network("gpu:0", "test_frontend", 6, (84, 84, 4), max_batch=64, predict_lanes=2)
+    yield n
+    n.close()
+
+
+def golden():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "frontend.npz"))
+    return {k[4:]: (g[k], g["plane_" + k[4:]]) for k in g.files if k.startswith("rgb_")}
+
+
+def atari_like(rng, n, shape=(210, 160, 3)):
+    """Frames with the structure that matters to bytescale / the resampler: flat fields, sprites, noise, narrow range."""
+    out = np.empty((n,) + shape, np.uint8)
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            out[i] = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        elif kind == 1:
+            out[i] = rng.integers(0, 256, size=(1, 1, shape[2]), dtype=np.uint8)
+            for _ in range(6):
+                y, x = rng.integers(0, shape[0] - 16), rng.integers(0, shape[1] - 8)
+                out[i, y:y + rng.integers(1, 16), x:x + rng.integers(1, 8)] = rng.integers(0, 256, size=shape[2], dtype=np.uint8)
+        elif kind == 2:
+            out[i] = (100 + rng.integers(0, 4, size=shape)).astype(np.uint8)
+        else:
+            out[i] = rng.integers(0, 256, size=shape[2], dtype=np.uint8)          # constant frame: max == min
+    return out
+
+
+def test_golden_planes(net):
+    g = golden()
+    for name, (rgb, plane) in g.items():
+        net.frames_config(4, *rgb.shape)
+        got = net.preprocess_frames(rgb)
+        assert got.shape == (1, 84, 84) and got.dtype == np.uint8
+        assert np.array_equal(got[0], plane), name
+
+
+@pytest.mark.parametrize("shape", [(210, 160, 3), (210, 160, 4), (250, 160, 3), (96, 96, 3), (84, 84, 3), (60, 200, 3)])
+def test_preprocess_equals_oracle(net, shape):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1] + shape[2])
+    n = 21
+    rgb = atari_like(rng, n, shape)
+    net.frames_config(32, *shape)
+    got = net.preprocess_frames(rgb)
+    for i in range(n):
+        assert np.array_equal(got[i], ff.preprocess_u8(rgb[i])), "frame %d of %s" % (i, shape)
+
+
+def test_frame_queue_and_prediction_from_device_states(net):
+    rng = np.random.default_rng(11)
+    n_agents, steps = 9, 7
+    net.frames_config(16, 210, 160, 3)
+    queues = [ff.FrameQueue() for _ in range(n_agents)]
+    ids = np.array([3, 0, 7, 12, 5, 9, 15, 1, 8], np.int32)           # queue rows are not the batch rows
+    for t in range(steps):
+        rgb = atari_like(rng, n_agents)
+        reset = np.zeros(n_agents, np.uint8)
+        if t == 0:
+            reset[:] = 1
+        if t == 5:
+            reset[2] = 1                                                  # one episode ends: its queue starts over
+        net.push_frames(rgb, ids, reset)
+        for k in range(n_agents):
+            if reset[k]:
+                queues[k].clear()
+            queues[k].push(ff.preprocess_u8(rgb[k]))
+            state, depth = net.frame_state(ids[k])
+            want = queues[k].state_u8()
+            assert depth == len(queues[k].q)
+            assert (state is None) == (want is None)
+            if want is not None:
+                assert np.array_equal(state, want)
+    ready = [k for k in range(n_agents) if queues[k].state_u8() is not None]
+    assert 2 not in ready and len(ready) == n_agents - 1
+    states = np.stack([queues[k].state_u8() for k in ready])
+    p, v = net.predict_frames(ids[ready])
+    p2, v2 = net.predict_p_and_v(states)                                  # the same bytes through the host-buffer path
+    assert np.array_equal(p, p2) and np.array_equal(v, v2)
+    with pytest.raises(RuntimeError, match="no state yet"):
+        net.predict_frames(ids[[2]])
+    with pytest.raises(RuntimeError, match="twice"):
+        net.push_frames(rgb[:2], np.array([4, 4], np.int32))
+    with pytest.raises(RuntimeError, match="outside"):
+        net.push_frames(rgb[:1], np.array([16], np.int32))
+
+
+def test_frames_read_in_place_from_pinned_and_registered_memory(net):
+    import Transport as tp
+    rng = np.random.default_rng(5)
+    net.frames_config(8, 210, 160, 3)
+    rgb = atari_like(rng, 5)
+    want = net.preprocess_frames(rgb)                                     # pageable -> staged
+    pinned = net.pinned_array(rgb.shape, np.uint8)
+    pinned[:] = rgb
+    assert np.array_equal(net.preprocess_frames(pinned), want)
+    # frames lying in the shared-memory transport (an agent's slot is big enough for one 100,800-byte frame)
+    t = tp.Transport.create(tp.unique_name("t_fr"), 4, 6, 4 * 84 * 84 * 4, 2, 6)
+    try:
+        net.register_transport(t)
+        slot = t.state_view(1)[:210 * 160 * 3].reshape(1, 210, 160, 3)
+        slot[:] = rgb[3]
+        assert np.array_equal(net.preprocess_frames(slot)[0], want[3])
+    finally:
+        net.unregister_transport()
+        t.shutdown()
+        t.close()
+
+
+def test_frames_need_config(net):
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    fresh = Network("gpu:0", "test_frontend2", 4, (84, 84, 4), max_batch=8, predict_lanes=1)
+    try:
+        fresh._frame_shape = (210, 160, 3)
+        with pytest.raises(RuntimeError, match="frames_config first"):
+            fresh.preprocess_frames(np.zeros((210, 160, 3), np.uint8))
+        with pytest.raises(RuntimeError):
+            fresh.frames_config(4, 210, 160, 2)
+    finally:
+        fresh.close()
