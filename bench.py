@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 FLOP_PER_PREDICTION = {4: 7_580_160, 6: 7_581_184, 18: 7_587_328}
 FLOP_CONV1_PER_SAMPLE = 3_612_672                                       # 441 * 256 * 16 * 2
 FLOP_CONV2_PER_SAMPLE = 1_982_464                                       # 121 * 256 * 32 * 2
+HBM_PEAK_GBS = 8000.0                                                   # MI355X_MICROARCH.md, HBM3E
 MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
 
 
@@ -324,6 +325,42 @@ def main():
         out["train"]["hogwild_lanes"] = dict(res, unit="steps/s", note="Config.HOGWILD: NT train lanes update the weights "
                                              "concurrently and unlocked like the reference's trainer threads; the headline "
                                              "train figure above is the synchronous single-lane mode")
+        # ---- frame front-end: raw 210x160x3 frames -> uint8 planes -> device frame queues
+        nf = 256                                            # one workgroup per frame, one frame per CU
+        frng = np.random.Generator(np.random.PCG64(Config.RANDOM_SEED + 99))
+        frames = frng.integers(0, 256, size=(nf, 210, 160, 3), dtype=np.uint8)
+        hog.frames_config(nf, 210, 160, 3)
+        nat.check(hog._lib.ga3c_net_frames_upload(hog._h, nat.ptr(frames, nat.u8p), nf), "frames_upload")
+        nat.check(hog._lib.ga3c_net_time_frames(hog._h, nf, 5, nat.C.byref(ms)), "time_frames")
+        nat.check(hog._lib.ga3c_net_time_frames(hog._h, nf, 50, nat.C.byref(ms)), "time_frames")
+        us = ms.value * 1e3 / 50
+        fbytes = 210 * 160 * 3 + 2 * 28224                   # frame in; the agent's queue read and written back
+        fe = {"frames_per_sec": nf / (us * 1e-6), "frames_per_launch": nf, "launch_us": us,
+              "roofline": {"kernel": "frame_frontend_kernel<true>", "bound": "hbm", "achieved": nf * fbytes / (us * 1e-6) / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nf * fbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "algorithmic_bytes_per_frame": fbytes, "traffic": None},
+              "note": "frames resident in HBM; gray (f64) + per-frame min/max bytescale + Pillow-exact bilinear 84x84 + push "
+                      "into the device-side 4-deep queues; bit-exact with oracle/frame_frontend.py"}
+        if args.cpu_seconds > 0:
+            import frame_frontend as ff
+            host = nat.host_lib()
+            plane = np.empty((84, 84), np.uint8)
+            k, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < min(args.cpu_seconds, 3.0):
+                ff.preprocess_u8(frames[k % nf])
+                k += 1
+            dt_o = time.perf_counter() - t0
+            j, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < 1.0:
+                host.ga3c_frame_preprocess(nat.ptr(frames[j % nf], nat.u8p), 210, 160, 3, 84, 84, nat.ptr(plane, nat.u8p))
+                j += 1
+            dt_h = time.perf_counter() - t0
+            fe["cpu_baseline"] = {"value": k / dt_o, "unit": "frames/s", "cores": 1, "kind": "port",
+                                  "sample": "%d frames through oracle/frame_frontend.py (numpy) in %.1f s" % (k, dt_o),
+                                  "host_c_frames_per_sec": j / dt_h,
+                                  "host_c_note": "ga3c_frame_preprocess (libga3c_host.so), one thread: what an actor "
+                                                 "process would otherwise spend per emulator frame"}
+        out["frontend"] = fe
         hog.close()
 
     # ---- whole engine, BASELINE configs[1]/[2] shape: agents -> shm transport -> ThreadPredictor / ThreadTrainer -> HIP

@@ -103,7 +103,6 @@ struct Frames {
   bool on = false;
   int maxA = 0, H = 0, W = 0, C = 0, hks = 0, vks = 0;
   size_t frame_bytes = 0, lds = 0;
-  bool cache = false;
   int32_t* d_tab = nullptr;            // hb | hk | vb | vk
   const int32_t *hb = nullptr, *hk = nullptr, *vb = nullptr, *vk = nullptr;
   uint32_t* stacks = nullptr;          // [maxA][84*84] words = [84,84,4] uint8 HWC states
@@ -444,10 +443,9 @@ int launch_frames(ga3c_net* net, const uint8_t* rgb_dev, const int32_t* agents, 
   a.rgb = rgb_dev; a.agents = agents; a.reset = reset; a.planes = planes; a.stacks = f.stacks;
   a.hb = f.hb; a.hk = f.hk; a.vb = f.vb; a.vk = f.vk;
   a.H = f.H; a.W = f.W; a.C = f.C; a.OH = IMG; a.OW = IMG; a.hks = f.hks; a.vks = f.vks;
-  const bool cache = f.cache && (reinterpret_cast<uintptr_t>(rgb_dev) & 3) == 0;
-  const size_t lds = frontend_lds_bytes(f.H, f.W, f.C, IMG, IMG, f.hks, f.vks, cache);
-  if (cache) hipLaunchKernelGGL(frame_frontend_kernel<true>, dim3(n), dim3(FE_THREADS), lds, f.st, a);
-  else hipLaunchKernelGGL(frame_frontend_kernel<false>, dim3(n), dim3(FE_THREADS), lds, f.st, a);
+  if (reinterpret_cast<uintptr_t>(rgb_dev) & 3) return fail(GA3C_EINVAL, "frames: the frame buffer must be 4-byte aligned");
+  if (f.C == 3) hipLaunchKernelGGL(frame_frontend_kernel<3>, dim3(n), dim3(FE_THREADS), f.lds, f.st, a);
+  else hipLaunchKernelGGL(frame_frontend_kernel<4>, dim3(n), dim3(FE_THREADS), f.lds, f.st, a);
   HIPCHK(hipGetLastError());
   return GA3C_OK;
 }
@@ -904,13 +902,15 @@ int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, in
   const ResampleTable th = make_bilinear_table(width, IMG), tv = make_bilinear_table(height, IMG);
   f.maxA = max_agents; f.H = height; f.W = width; f.C = channels; f.hks = th.ksize; f.vks = tv.ksize;
   f.frame_bytes = (size_t)height * width * channels;
-  const size_t lds_cache = frontend_lds_bytes(height, width, channels, IMG, IMG, f.hks, f.vks, true);
-  f.cache = f.frame_bytes % 4 == 0 && lds_cache <= 158 * 1024;
-  f.lds = frontend_lds_bytes(height, width, channels, IMG, IMG, f.hks, f.vks, f.cache);
-  if (f.lds > 158 * 1024) return fail(GA3C_EINVAL, "frames: a %dx%d frame does not fit the kernel's LDS plan", height, width);
-  for (const void* fn : {reinterpret_cast<const void*>(&frame_frontend_kernel<true>),
-                         reinterpret_cast<const void*>(&frame_frontend_kernel<false>)})
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(158 * 1024)));
+  const int64_t npx = (int64_t)height * width;
+  if (npx % 4 || npx > (int64_t)4 * FE_MAXG * FE_THREADS)
+    return fail(GA3C_EINVAL, "frames: height*width must be a multiple of 4 and at most %d", 4 * FE_MAXG * FE_THREADS);
+  if (th.ksize > FE_MAXK) return fail(GA3C_EINVAL, "frames: width %d needs %d taps per output, the kernel holds %d", width, th.ksize, FE_MAXK);
+  f.lds = frontend_lds_bytes(height, width, IMG, IMG, f.vks);
+  if (f.lds > 150 * 1024) return fail(GA3C_EINVAL, "frames: a %dx%d frame does not fit the kernel's LDS plan", height, width);
+  for (const void* fn : {reinterpret_cast<const void*>(&frame_frontend_kernel<3>),
+                         reinterpret_cast<const void*>(&frame_frontend_kernel<4>)})
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024)));
   std::vector<int32_t> tab;
   tab.insert(tab.end(), th.bounds.begin(), th.bounds.end());
   tab.insert(tab.end(), th.kk.begin(), th.kk.end());

@@ -8,12 +8,13 @@
 //   queue : one uint32 per pixel, byte c = plane c, oldest first -> push = (word >> 8) | (plane << 24); the words
 //           ARE the [84,84,4] uint8 HWC state the conv kernels consume.
 //
-// One workgroup (1024 threads) per frame.  Byte work bounded by memory: the 100,800 frame bytes are fetched ONCE
-// (dword loads, coalesced) into LDS -- the min/max pass and the bytescale pass both read that copy -- the 8-bit
-// gray image (33.6 KB) and the horizontal-pass image (17.6 KB, aliased onto the dead RGB copy) stay in LDS, and
-// the only other HBM traffic is the queue's read-modify-write (28 KB each way).  Frames too big for that LDS
-// budget (e.g. 250x160) re-read the RGB bytes from L2 instead (CACHE = false).
-// Algorithmic bytes per frame: H*W*C in + 2 * 28,224 queue + 7,056 plane (when asked for).
+// One workgroup (1024 threads) per frame.  Byte work bounded by memory, so every byte moves once: a thread loads
+// its share of the frame -- up to FE_MAXG groups of 4 pixels = 12 (RGB) or 16 (RGBA) contiguous bytes each, all
+// loads issued back to back -- straight into registers, keeps the f64 gray values there across the block-wide
+// min/max reduction, and writes the 8-bit image into LDS (33.6 KB).  The horizontal pass gives each thread one
+// fixed group of 4 output columns, so its taps sit in registers while it walks down the rows; the vertical pass
+// reads 4 pixels per LDS dword.  The only other HBM traffic is the queue's read-modify-write (28 KB each way).
+// Algorithmic bytes per frame: H*W*C in + 2 * 28,224 queue (+ 7,056 when the plane itself is asked for).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,53 +39,66 @@ __device__ __forceinline__ double fe_gray(uint32_t r, uint32_t g, uint32_t b) {
 }
 
 __device__ __forceinline__ uint32_t fe_clip8(int32_t acc) {
-  const int32_t v = acc >> FE_PRECISION_BITS;
+  int32_t v = acc >> FE_PRECISION_BITS;
+  // Keep the shift and the clamp apart: fused, ROCm 7.2's gfx950 backend pairs two of these into v_ashr_pk_u8_i32,
+  // whose result it then ORs with further bytes as if bits 16..31 were zero -- they are not (seen as wrong pixels
+  // 2 and 3 of every packed dword; tests/test_gpu_frontend.py catches it).
+  asm volatile("" : "+v"(v));
   return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-// gray of pixel i from a byte array (LDS copy or global memory)
-template <typename P>
-__device__ __forceinline__ double fe_gray_at(P bytes, int i, int C) {
-  const int o = i * C;
-  return fe_gray(bytes[o], bytes[o + 1], bytes[o + 2]);
+constexpr int FE_MAXG = 10;        // pixel groups per thread: frames up to 4 * 10 * 1024 = 40,960 pixels (250 x 160 fits)
+constexpr int FE_MAXK = 8;         // taps per output the register-resident horizontal pass holds (downscale <= 3.5x)
+static_assert(FE_MAXK == 8, "the horizontal pass reads exactly two shifted dwords of source bytes per output");
+
+// 4 consecutive pixels' r, g, b out of their 12 (C = 3) or 16 (C = 4) contiguous bytes
+template <int C>
+__device__ __forceinline__ void fe_load4(const uint8_t* p, double (&g)[4]) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+  if (C == 3) {
+    const uint32_t a = w[0], b = w[1], c = w[2];
+    g[0] = fe_gray(a & 255u, (a >> 8) & 255u, (a >> 16) & 255u);
+    g[1] = fe_gray(a >> 24, b & 255u, (b >> 8) & 255u);
+    g[2] = fe_gray((b >> 16) & 255u, b >> 24, c & 255u);
+    g[3] = fe_gray((c >> 8) & 255u, (c >> 16) & 255u, c >> 24);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = fe_gray(w[q] & 255u, (w[q] >> 8) & 255u, (w[q] >> 16) & 255u);
+  }
 }
 
-template <bool CACHE>
+template <int C>
 __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a) {
   extern __shared__ __align__(16) uint8_t fe_lds[];
   const int tid = threadIdx.x, f = blockIdx.x;
-  const int npx = a.H * a.W, nbytes = npx * a.C;
+  const int npx = a.H * a.W, ngrp = npx / 4;            // npx % 4 == 0 (checked on the host)
   const int nout = a.OH * a.OW;
-  // LDS map: [tables][g8: npx][scratch: max(CACHE ? nbytes : 0, H*OW)]
-  int32_t* t_hb = reinterpret_cast<int32_t*>(fe_lds);
-  int32_t* t_hk = t_hb + a.OW * 2;
-  int32_t* t_vb = t_hk + a.OW * a.hks;
+  // LDS map: [vertical tables][g8: npx][tmp: H*OW]
+  int32_t* t_vb = reinterpret_cast<int32_t*>(fe_lds);
   int32_t* t_vk = t_vb + a.OH * 2;
-  const int tab_bytes = ((a.OW * (2 + a.hks) + a.OH * (2 + a.vks)) * 4 + 15) & ~15;
+  const int tab_bytes = (a.OH * (2 + a.vks) * 4 + 15) & ~15;
   uint8_t* g8 = fe_lds + tab_bytes;
-  uint8_t* scratch = g8 + ((npx + 15) & ~15);
+  uint8_t* tmp = g8 + ((npx + 15) & ~15);
   __shared__ double red_min[FE_THREADS / 64], red_max[FE_THREADS / 64];
 
-  for (int i = tid; i < a.OW * 2; i += FE_THREADS) t_hb[i] = a.hb[i];
-  for (int i = tid; i < a.OW * a.hks; i += FE_THREADS) t_hk[i] = a.hk[i];
   for (int i = tid; i < a.OH * 2; i += FE_THREADS) t_vb[i] = a.vb[i];
   for (int i = tid; i < a.OH * a.vks; i += FE_THREADS) t_vk[i] = a.vk[i];
 
-  const uint8_t* src = a.rgb + (size_t)f * nbytes;
-  if (CACHE) {   // nbytes % 4 == 0 and the frame base is 4-byte aligned (checked on the host)
-    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(scratch);
-    for (int i = tid; i < nbytes / 4; i += FE_THREADS) d32[i] = s32[i];
-    __syncthreads();
-  }
-  const uint8_t* px = CACHE ? scratch : src;
-
-  // ---- pass 1: per-frame min / max of the f64 gray image
+  // ---- pass 1: the frame's bytes -> f64 gray in registers; per-frame min / max
+  const uint8_t* src = a.rgb + (size_t)f * npx * C;
+  double gray[FE_MAXG][4];
   double lo = 1e300, hi = -1e300;
-  for (int i = tid; i < npx; i += FE_THREADS) {
-    const double g = fe_gray_at(px, i, a.C);
-    lo = g < lo ? g : lo;
-    hi = g > hi ? g : hi;
+#pragma unroll
+  for (int j = 0; j < FE_MAXG; ++j) {
+    const int grp = tid + j * FE_THREADS;
+    if (grp < ngrp) {
+      fe_load4<C>(src + (size_t)grp * 4 * C, gray[j]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        lo = gray[j][q] < lo ? gray[j][q] : lo;
+        hi = gray[j][q] > hi ? gray[j][q] : hi;
+      }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const double l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
@@ -106,33 +120,65 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   if (cscale == 0.0) cscale = 1.0;
   const double scale = 255.0 / cscale;
 
-  // ---- pass 2: bytescale -> 8-bit gray image in LDS
-  for (int i = tid; i < npx; i += FE_THREADS) {
-    double t = __dmul_rn(__dsub_rn(fe_gray_at(px, i, a.C), lo), scale);
-    t = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
-    g8[i] = (uint8_t)(int)__dadd_rn(t, 0.5);
-  }
-  __syncthreads();   // g8 complete; the RGB copy in `scratch` is dead from here on
-
-  // ---- pass 3: horizontal resample g8[H][W] -> tmp[H][OW]   (4 adjacent outputs per thread, one dword store)
-  const uint8_t* hsrc = g8;
-  int cur_w = a.W;
-  if (a.W != a.OW) {
-    const int groups = a.OW / 4;
-    for (int i = tid; i < a.H * groups; i += FE_THREADS) {
-      const int y = i / groups, x0 = (i - y * groups) * 4;
+  // ---- pass 2: bytescale -> 8-bit gray image in LDS, 4 pixels per dword store
+#pragma unroll
+  for (int j = 0; j < FE_MAXG; ++j) {
+    const int grp = tid + j * FE_THREADS;
+    if (grp < ngrp) {
       uint32_t packed = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int xx = x0 + q, xmin = t_hb[xx * 2], n = t_hb[xx * 2 + 1];
-        int32_t acc = 1 << (FE_PRECISION_BITS - 1);
-        for (int k = 0; k < n; ++k) acc += (int32_t)g8[y * a.W + xmin + k] * t_hk[xx * a.hks + k];
-        packed |= fe_clip8(acc) << (8 * q);
+        double t = __dmul_rn(__dsub_rn(gray[j][q], lo), scale);
+        t = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
+        packed |= (uint32_t)(int)__dadd_rn(t, 0.5) << (8 * q);
       }
-      reinterpret_cast<uint32_t*>(scratch)[i] = packed;
+      reinterpret_cast<uint32_t*>(g8)[grp] = packed;
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 3: horizontal resample g8[H][W] -> tmp[H][OW].  Thread = one group of 4 output columns (taps and
+  //      bounds in registers), walking down the rows `lanes_y` apart.
+  const uint8_t* hsrc = g8;
+  int cur_w = a.W;
+  const int groups = a.OW / 4;
+  if (a.W != a.OW) {
+    const int lanes_y = FE_THREADS / groups;
+    const int grp = tid % groups, y0 = tid / groups;
+    int xmin[4], tap[4][FE_MAXK];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int xx = grp * 4 + q, n = a.hb[xx * 2 + 1];
+      xmin[q] = a.hb[xx * 2];
+#pragma unroll
+      for (int k = 0; k < FE_MAXK; ++k) tap[q][k] = (k < a.hks && k < n) ? a.hk[xx * a.hks + k] : 0;
+    }
+    if (y0 < lanes_y) {
+      for (int y = y0; y < a.H; y += lanes_y) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // the <= 8 source bytes of this output as three ALIGNED LDS dwords, shifted into place (byte-granular
+          // LDS reads would be merged by the compiler into wide reads at odd addresses); taps past the count are 0,
+          // so whatever lies behind the last real tap is multiplied away
+          const int idx = y * a.W + xmin[q];
+          const uint32_t* w = reinterpret_cast<const uint32_t*>(g8 + (idx & ~3));
+          const uint32_t sh = (uint32_t)(idx & 3) * 8;
+          const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+          const uint32_t b03 = __funnelshift_r(w0, w1, sh), b47 = __funnelshift_r(w1, w2, sh);
+          int32_t acc = 1 << (FE_PRECISION_BITS - 1);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            acc += (int32_t)((b03 >> (8 * k)) & 255u) * tap[q][k];
+            acc += (int32_t)((b47 >> (8 * k)) & 255u) * tap[q][4 + k];
+          }
+          packed |= fe_clip8(acc) << (8 * q);
+        }
+        reinterpret_cast<uint32_t*>(tmp)[y * groups + grp] = packed;
+      }
     }
     __syncthreads();
-    hsrc = scratch;
+    hsrc = tmp;
     cur_w = a.OW;
   }
 
@@ -141,9 +187,11 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   const bool clear = a.reset && a.reset[f];
   uint32_t* stack = agent >= 0 ? a.stacks + (size_t)agent * nout : nullptr;
   uint8_t* plane = a.planes ? a.planes + (size_t)f * nout : nullptr;
-  const int groups = a.OW / 4;
   for (int i = tid; i < a.OH * groups; i += FE_THREADS) {
     const int yy = i / groups, x0 = (i - yy * groups) * 4;
+    const int p0 = yy * a.OW + x0;
+    uint4 s = make_uint4(0, 0, 0, 0);
+    if (stack && !clear) s = *reinterpret_cast<const uint4*>(stack + p0);   // issued before the taps are walked
     uint32_t v4[4];
     if (a.H != a.OH) {
       const int ymin = t_vb[yy * 2], n = t_vb[yy * 2 + 1];
@@ -163,10 +211,8 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) v4[q] = (w4 >> (8 * q)) & 255u;
     }
-    const int p0 = yy * a.OW + x0;
     if (plane) *reinterpret_cast<uint32_t*>(plane + p0) = v4[0] | (v4[1] << 8) | (v4[2] << 16) | (v4[3] << 24);
     if (stack) {
-      uint4 s = clear ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(stack + p0);
       s.x = (s.x >> 8) | (v4[0] << 24);
       s.y = (s.y >> 8) | (v4[1] << 24);
       s.z = (s.z >> 8) | (v4[2] << 24);
@@ -177,12 +223,10 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
 }
 
 // bytes of dynamic LDS the kernel needs for a frame geometry
-inline size_t frontend_lds_bytes(int H, int W, int C, int OH, int OW, int hks, int vks, bool cache) {
-  const size_t tab = ((size_t)(OW * (2 + hks) + OH * (2 + vks)) * 4 + 15) & ~(size_t)15;
+inline size_t frontend_lds_bytes(int H, int W, int OH, int OW, int vks) {
+  const size_t tab = ((size_t)OH * (2 + vks) * 4 + 15) & ~(size_t)15;
   const size_t g8 = ((size_t)H * W + 15) & ~(size_t)15;
-  size_t scratch = (size_t)H * OW;
-  if (cache && (size_t)H * W * C > scratch) scratch = (size_t)H * W * C;
-  return tab + g8 + ((scratch + 15) & ~(size_t)15);
+  return tab + g8 + (((size_t)H * OW + 15) & ~(size_t)15);
 }
 
 }  // namespace ga3c
