@@ -335,10 +335,14 @@ def main():
         nat.check(hog._lib.ga3c_net_time_frames(hog._h, nf, 50, nat.C.byref(ms)), "time_frames")
         us = ms.value * 1e3 / 50
         fbytes = 210 * 160 * 3 + 2 * 28224                   # frame in; the agent's queue read and written back
+        fe_traffic = None                                     # PMC-derived HBM bytes per launch (profiles/r01_l_frontend_pmc.md)
+        if os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")):
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                fe_traffic = json.load(f).get("frame_frontend_210x160x3_n%d" % nf)
         fe = {"frames_per_sec": nf / (us * 1e-6), "frames_per_launch": nf, "launch_us": us,
               "roofline": {"kernel": "frame_frontend_kernel<true>", "bound": "hbm", "achieved": nf * fbytes / (us * 1e-6) / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nf * fbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                           "algorithmic_bytes_per_frame": fbytes, "traffic": None},
+                           "algorithmic_bytes_per_frame": fbytes, "traffic": fe_traffic},
               "note": "frames resident in HBM; gray (f64) + per-frame min/max bytescale + Pillow-exact bilinear 84x84 + push "
                       "into the device-side 4-deep queues; bit-exact with oracle/frame_frontend.py"}
         if args.cpu_seconds > 0:
