@@ -308,7 +308,7 @@ def main():
                                          "OpenMP over %d threads of %d host cores" % (n, B, dt, oc.threads(), os.cpu_count()),
                                "train_steps_per_sec": m / dt2}
 
-    cpu_theta = net.get_arena(0) if "cpu_baseline" in out else None
+    cpu_theta = net.get_arena(0) if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
     net.close()
 
     # ---- Hogwild trainers: the reference's default NT = 2 trainer threads update shared weights unlocked (Server.py:132-134)

@@ -20,6 +20,7 @@
 #include <new>
 #include <shared_mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ga3c_abi.h"
@@ -74,11 +75,15 @@ struct Lane {
   Fwd f;
   float* h_in = nullptr;    // pinned staging, max_batch states
   float* h_out = nullptr;   // pinned staging, p|v|z
-  int64_t* h_off = nullptr; // pinned: per-row byte offsets for gather_states_kernel
-  int64_t* d_off = nullptr;
+  int64_t* h_off = nullptr; // pinned: per-row byte offsets, read in place by the gather kernels
   hipEvent_t read_done[2] = {nullptr, nullptr};
   bool dirty[2] = {false, false};   // read_done[i] recorded since theta[i] was last written (guarded by wmu)
+  // captured prediction steps, one executable graph per (batch, weight buffer, intake mode, output target): every
+  // pointer a step touches is fixed for the lane's lifetime, so a step is replayed with ONE launch call
+  std::unordered_map<int64_t, hipGraphExec_t> graphs;
 };
+
+enum StepMode { STEP_RESIDENT = 0, STEP_GATHER_U8 = 1, STEP_GATHER_F32 = 2, STEP_QUEUES = 3 };
 
 struct TrainLane {
   std::mutex mu;
@@ -89,7 +94,6 @@ struct TrainLane {
   float* h_in = nullptr;    // pinned: x | y_r | a
   float* h_out = nullptr;   // pinned: p | v | z | losses
   int64_t* h_off = nullptr;
-  int64_t* d_off = nullptr;
   float* grad = nullptr;    // this lane's gradient arena (lane 0: net->grad, the buffer RCCL all-reduces)
   bool owns_grad = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -140,6 +144,9 @@ struct ga3c_net {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
+  bool graphs = false;                 // GA3C_GRAPHS=1: prediction steps replayed as hipGraphs.  Off by default: on ROCm 7.2 a
+                                       // 4-kernel graph launch costs ~6 us MORE per step than four plain launches and
+                                       // two lanes lose 10 % of their overlap (profiles/README.md, round 1)
   void* reg_host = nullptr;            // HIP-registered host segment (the shm transport) ...
   uint8_t* reg_dev = nullptr;          // ... and the device-side address of its first byte
   int64_t reg_bytes = 0;
@@ -289,7 +296,54 @@ int launch_rmsprop(ga3c_net* net, const float* grad, float* scales, const float*
 }
 
 // forward on a prediction lane: pick the current weights under the shared lock
-int lane_forward(ga3c_net* net, Lane& L, int B, float* out_p, float* out_v) {
+// the kernels of one prediction step on lane L: the intake gather (offsets already in L.h_off), then the forward pass
+int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v) {
+  if (mode != STEP_RESIDENT) {
+    const bool u8 = mode != STEP_GATHER_F32;
+    const uint8_t* base = mode == STEP_QUEUES ? reinterpret_cast<const uint8_t*>(net->fr.stacks) : net->reg_dev;
+    const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.xu8, B);
+    else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.x, B);
+    L.f.x_u8 = u8;
+  }
+  return launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
+}
+
+void drop_graphs(Lane& L) {
+  for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
+  L.graphs.clear();
+}
+
+// launch_step, replayed from the lane's graph cache (captured on first use of a shape)
+int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v) {
+  if (!net->graphs) return launch_step(net, L, idx, B, mode, out_p, out_v);
+  const bool u8 = mode == STEP_RESIDENT ? L.f.x_u8 : mode != STEP_GATHER_F32;
+  const int64_t key = ((int64_t)B << 8) | (idx << 5) | (mode << 2) | (u8 ? 2 : 0) | (out_p ? 1 : 0);
+  auto it = L.graphs.find(key);
+  if (it == L.graphs.end()) {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ex = nullptr;
+    HIPCHK(hipStreamBeginCapture(L.st, hipStreamCaptureModeThreadLocal));
+    const int rc = launch_step(net, L, idx, B, mode, out_p, out_v);
+    const hipError_t e = hipStreamEndCapture(L.st, &g);
+    if (rc != GA3C_OK) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc;
+    }
+    if (e != hipSuccess) return fail(GA3C_EHIP, "stream capture of a prediction step failed: %s", hipGetErrorString(e));
+    const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) return fail(GA3C_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    it = L.graphs.emplace(key, ex).first;
+  }
+  L.f.x_u8 = u8;
+  HIPCHK(hipGraphLaunch(it->second, L.st));
+  return GA3C_OK;
+}
+
+int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* out_v) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->cur;
   {
@@ -301,7 +355,7 @@ int lane_forward(ga3c_net* net, Lane& L, int B, float* out_p, float* out_v) {
     }
   }
   HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
-  CHK(launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v));
+  CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
   return GA3C_OK;
@@ -383,8 +437,8 @@ int read_losses(ga3c_net*, TrainLane& t, float* losses) {
 }
 
 // rows of a batch gathered from the registered host segment into x (device), on stream st
-int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off, int64_t* d_off, Fwd& f,
-                  hipStream_t st) {
+// per-row byte offsets into the registered host segment, validated and copied into the lane's pinned array
+int stage_offsets(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off) {
   if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int64_t sb = (int64_t)XS * (u8 ? 1 : 4);
@@ -393,7 +447,13 @@ int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
       return fail(GA3C_EINVAL, "row %d: offset %lld outside the registered segment or not 16-byte aligned", i, (long long)offsets[i]);
     h_off[i] = offsets[i];
   }
-  (void)d_off;   // the gather kernel reads the offsets out of the pinned host array itself: no H2D copy to wait for
+  return GA3C_OK;
+}
+
+// rows of a batch gathered from the registered host segment into x (device), on stream st; the gather kernel reads
+// the offsets out of the pinned host array itself: no H2D copy to wait for
+int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off, Fwd& f, hipStream_t st) {
+  CHK(stage_offsets(net, offsets, B, u8, h_off));
   const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
@@ -402,6 +462,14 @@ int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
   f.x_u8 = u8;
   HIPCHK(hipGetLastError());
   return GA3C_OK;
+}
+
+// captured steps hold the addresses of the registered segment / the frame queues: forget them when those move
+void drop_all_graphs(ga3c_net* net) {
+  for (Lane* L : net->lanes) {
+    std::lock_guard<std::mutex> g(L->mu);
+    drop_graphs(*L);
+  }
 }
 
 void free_frames(Frames& f) {
@@ -461,13 +529,13 @@ Lane* take_lane(ga3c_net* net) {
   return L;
 }
 
-int finish_predict(ga3c_net* net, Lane* L, int B, float* p, float* v, float* z) {
+int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, float* z) {
   const int A = net->A;
   float* hp = L->h_out;
   float* hv = hp + (size_t)net->maxB * A;
   float* hz = hv + net->maxB;
   // the heads kernel stores p and v straight into the lane's pinned host buffer: no D2H copies on the round trip
-  CHK(lane_forward(net, *L, B, hp, hv));
+  CHK(lane_forward(net, *L, B, mode, hp, hv));
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
   HIPCHK(hipStreamSynchronize(L->st));
   memcpy(p, hp, (size_t)B * A * sizeof(float));
@@ -501,7 +569,7 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
     }
     L->f.x_u8 = false;
   }
-  return finish_predict(net, L, B, p, v, z);
+  return finish_predict(net, L, B, STEP_RESIDENT, p, v, z);
 }
 
 // Lane for one train call.  Synchronous mode: lane 0, callers queue on its mutex.  Hogwild mode: any free lane.
@@ -551,7 +619,6 @@ int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
   HIPCHK(hipEventCreate(&t.ev0));
   HIPCHK(hipEventCreate(&t.ev1));
   HIPCHK(hipHostMalloc((void**)&t.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
-  HIPCHK(hipMalloc((void**)&t.d_off, (size_t)maxB * sizeof(int64_t)));
   return GA3C_OK;
 }
 
@@ -563,7 +630,6 @@ void free_train_lane(TrainLane& t) {
   if (t.h_in) (void)hipHostFree(t.h_in);
   if (t.h_out) (void)hipHostFree(t.h_out);
   if (t.h_off) (void)hipHostFree(t.h_off);
-  if (t.d_off) (void)hipFree(t.d_off);
   if (t.ev0) (void)hipEventDestroy(t.ev0);
   if (t.ev1) (void)hipEventDestroy(t.ev1);
   if (t.st) (void)hipStreamDestroy(t.st);
@@ -607,6 +673,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (!net) return fail(GA3C_EINVAL, "out of host memory");
   net->cfg = *cfg;
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
+  net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (net->fused_conv) {
     const int lds = (int)(CS_LDS_FLOATS * sizeof(float));
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_stack_fwd_kernel<true, true>),
@@ -671,7 +738,6 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
     for (int k = 0; k < 2; ++k) TRYHIP(hipEventCreateWithFlags(&L->read_done[k], hipEventDisableTiming));
     TRYHIP(hipHostMalloc((void**)&L->h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
-    TRYHIP(hipMalloc((void**)&L->d_off, (size_t)maxB * sizeof(int64_t)));
   }
   TRY(alloc_train_lane(net, net->tr, net->grad));
   net->hogwild = cfg->train_lanes >= 2;
@@ -694,11 +760,11 @@ int ga3c_net_destroy(ga3c_net* net) {
   (void)hipDeviceSynchronize();
   if (net->comm) (void)ncclCommDestroy(net->comm);
   for (Lane* L : net->lanes) {
+    drop_graphs(*L);
     free_fwd(L->f);
     if (L->h_in) (void)hipHostFree(L->h_in);
     if (L->h_out) (void)hipHostFree(L->h_out);
     if (L->h_off) (void)hipHostFree(L->h_off);
-    if (L->d_off) (void)hipFree(L->d_off);
     for (int k = 0; k < 2; ++k)
       if (L->read_done[k]) (void)hipEventDestroy(L->read_done[k]);
     if (L->st) (void)hipStreamDestroy(L->st);
@@ -848,6 +914,7 @@ int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes) {
     (void)hipHostUnregister(base);
     return fail(GA3C_EHIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
   }
+  drop_all_graphs(net);
   net->reg_host = base;
   net->reg_dev = (uint8_t*)dev;
   net->reg_bytes = bytes;
@@ -859,6 +926,7 @@ int ga3c_net_unregister_host(ga3c_net* net) {
   if (!net->reg_host) return GA3C_OK;
   HIPCHK(hipSetDevice(net->cfg.device));
   CHK(sync_all(net));
+  drop_all_graphs(net);
   HIPCHK(hipHostUnregister(net->reg_host));
   net->reg_host = nullptr;
   net->reg_dev = nullptr;
@@ -872,8 +940,8 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
   HIPCHK(hipSetDevice(net->cfg.device));
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
-  CHK(launch_gather(net, offsets, batch, u8 != 0, L->h_off, L->d_off, L->f, L->st));
-  return finish_predict(net, L, batch, p, v, z);
+  CHK(stage_offsets(net, offsets, batch, u8 != 0, L->h_off));
+  return finish_predict(net, L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, p, v, z);
 }
 
 int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
@@ -883,7 +951,7 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   TrainLane* tp = take_train_lane(net);
   std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
   TrainLane& t = *tp;
-  CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.d_off, t.f, t.st));
+  CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.f, t.st));
   CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
   CHK(train_grads(net, t, batch, beta));
   CHK(train_apply(net, t, learning_rate));
@@ -897,6 +965,7 @@ int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, in
     return fail(GA3C_EINVAL, "frames: need max_agents >= 1, a positive frame size and 3 or 4 channels");
   HIPCHK(hipSetDevice(net->cfg.device));
   Frames& f = net->fr;
+  drop_all_graphs(net);
   std::lock_guard<std::mutex> g(f.mu);
   free_frames(f);
   const ResampleTable th = make_bilinear_table(width, IMG), tv = make_bilinear_table(height, IMG);
@@ -1011,14 +1080,7 @@ int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, flo
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   for (int i = 0; i < n; ++i) L->h_off[i] = (int64_t)agents[i] * XS;
-  const int64_t total = (int64_t)n * (XS / 16);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, L->st, reinterpret_cast<const uint8_t*>(f.stacks),
-                     L->h_off, L->f.xu8, n);
-  HIPCHK(hipGetLastError());
-  L->f.x_u8 = true;
-  return finish_predict(net, L, n, p, v, z);
+  return finish_predict(net, L, n, STEP_QUEUES, p, v, z);
 }
 
 int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n) {
@@ -1148,7 +1210,7 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   const auto h0 = std::chrono::steady_clock::now();
   for (int i = 0; i < iters; ++i) {
     Lane* L = net->lanes[i % nlanes];
-    CHK(launch_forward(net, L->f, idx, batch, L->st, false, nullptr, 0.f));
+    CHK(lane_step(net, *L, idx, batch, STEP_RESIDENT, nullptr, nullptr));
   }
   for (int l = 0; l < nlanes; ++l) HIPCHK(hipStreamSynchronize(net->lanes[l]->st));
   *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();

@@ -324,3 +324,51 @@ def test_network_helper_surface_matches_reference(nets, tmp_path, monkeypatch):
     net.set_arena(0, np.zeros_like(theta))
     monkeypatch.setattr(Config, "LOAD_EPISODE", 0)
     assert net.load() == 123 and np.array_equal(net.get_arena(0), theta)
+
+
+def test_graph_replayed_prediction_steps_are_bit_identical(nets, monkeypatch):
+    """GA3C_GRAPHS=1: gather + forward captured once per (batch, weight buffer, intake) and replayed with one launch
+    (BASELINE configs[4] names a hipGraph-captured predictor step).  Same kernels, same arguments -> same bits, also
+    after the optimizer flipped the weight buffer and after the transport was re-registered."""
+    import Transport as tp
+    from NetworkVP import Network
+    plain = nets(6)
+    monkeypatch.setenv("GA3C_GRAPHS", "1")
+    g = Network("gpu:0", "test_graphs", 6, (84, 84, 4), max_batch=160, predict_lanes=2)
+    monkeypatch.delenv("GA3C_GRAPHS")
+    try:
+        for net in (plain, g):
+            net.set_arena(0, _flat(o.init_params(6), 6))
+            net.set_arena(1, np.ones(net.param_count, np.float32))
+        for seed, bsz in ((1, 1), (2, 7), (3, 64), (4, 7), (5, 64)):            # repeats replay the cached graphs
+            xk, x, a, y = _batch(bsz, 6, seed)
+            for inp in (xk, x):
+                p0, v0 = plain.predict_p_and_v(inp)
+                p1, v1 = g.predict_p_and_v(inp)
+                assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+        xk, x, a, y = _batch(16, 6, 9)
+        for net in (plain, g):
+            net.learning_rate, net.beta = 3e-4, 0.01
+            net.train(x, y, a, None, None, 0)                                   # flips theta[cur]
+        assert np.array_equal(plain.get_arena(0), g.get_arena(0))
+        p0, v0 = plain.predict_p_and_v(xk)
+        p1, v1 = g.predict_p_and_v(xk)
+        assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+        for round_ in range(2):                                                 # second round: a NEW segment address
+            t = tp.Transport.create(tp.unique_name("t_graph"), 8, 6, 84 * 84 * 4, 2, 6)
+            try:
+                t.agent_states[:] = np.random.default_rng(round_).integers(0, 256, size=t.agent_states.shape, dtype=np.uint8)
+                ids = np.array([5, 1, 6], np.uint32)
+                want = plain.predict_p_and_v(np.ascontiguousarray(t.agent_states[ids]).reshape(3, 84, 84, 4))
+                g.register_transport(t)
+                for _ in range(2):
+                    got = g.predict_offsets(t.state_offsets(ids))
+                    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+                g.unregister_transport()
+            finally:
+                t.shutdown()
+                t.close()
+    finally:
+        g.close()
+        plain.set_arena(0, _flat(o.init_params(6), 6))
+        plain.set_arena(1, np.ones(plain.param_count, np.float32))

@@ -1,16 +1,21 @@
-"""Latency of one predictor round trip through the C ABI at small batch (development aid)."""
-import sys, time
-sys.path.insert(0, '.')
+"""Latency of one predictor round trip through the C ABI at small batch (development aid).
+
+    python tools/predict_latency.py            # plain launches (default)
+    GA3C_GRAPHS=1 python tools/predict_latency.py   # prediction steps replayed from captured hipGraphs
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ga3c_amd, Transport as tp
 from NetworkVP import Network
 
-t = tp.Transport.create(tp.unique_name("lat"), 64, 6, 84 * 84 * 4, 8, 6)
+t = tp.Transport.create(tp.unique_name("lat"), 128, 6, 84 * 84 * 4, 8, 6)
 net = Network("gpu:0", "lat", 6, (84, 84, 4), max_batch=128, predict_lanes=2)
 net.register_transport(t)
 rng = np.random.default_rng(0)
-t.agent_states[:] = rng.integers(0, 256, size=(64, 84 * 84 * 4), dtype=np.uint8)
-for n in (1, 8, 16, 32, 64):
+t.agent_states[:] = rng.integers(0, 256, size=(128, 84 * 84 * 4), dtype=np.uint8)
+print("graphs:", "on" if os.environ.get("GA3C_GRAPHS") else "off")
+for n in (1, 8, 16, 32, 64, 128):
     ids = np.arange(n, dtype=np.uint32)
     offs = t.state_offsets(ids)
     x = np.ascontiguousarray(t.agent_states[:n]).reshape(n, 84, 84, 4)
@@ -27,4 +32,4 @@ for n in (1, 8, 16, 32, 64):
         net.predict_p_and_v(x)
     b = (time.perf_counter() - t0) / 500 * 1e6
     print("batch %3d: zero-copy gather %.1f us per call, host-buffer u8 %.1f us per call" % (n, a, b))
-net.close(); t.shutdown(); t.close()
+net.unregister_transport(); net.close(); t.shutdown(); t.close()
