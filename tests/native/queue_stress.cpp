@@ -12,6 +12,19 @@
 #include "../../include/ga3c_host.h"
 
 static std::atomic<int> failures{0};
+static ga3c_shm* g_shm = nullptr;
+
+// stands in for ga3c_net_predict_gather in the native predictor loop (ga3c_pq_serve)
+static int fake_predict_rows(void*, const int64_t* offsets, int32_t batch, int32_t, float* p, float* v, float*) {
+  const unsigned char* base = (const unsigned char*)ga3c_shm_base(g_shm);
+  for (int i = 0; i < batch; ++i) {
+    int tag;
+    std::memcpy(&tag, base + offsets[i], 4);
+    v[i] = (float)tag;
+    for (int o = 0; o < 6; ++o) p[i * 6 + o] = (float)(tag % 7 + o);
+  }
+  return 0;
+}
 #define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s line %d\n", #c, __LINE__); failures++; } } while (0)
 
 int main(int argc, char** argv) {
@@ -23,8 +36,26 @@ int main(int argc, char** argv) {
   char name[64];
   std::snprintf(name, sizeof name, "/ga3c_tsan_%d", (int)getpid());
   REQUIRE(ga3c_shm_create(name, &cfg, &shm) == 0);
+  g_shm = shm;
+  {   // frame front-end under the sanitizers: odd geometries walk every bound of the two resample passes
+    const int geo[5][3] = {{210, 160, 3}, {250, 160, 4}, {40, 50, 3}, {84, 84, 3}, {7, 300, 3}};
+    for (auto& g : geo) {
+      std::vector<uint8_t> rgb((size_t)g[0] * g[1] * g[2]), plane(84 * 84);
+      for (size_t i = 0; i < rgb.size(); ++i) rgb[i] = (uint8_t)(i * 2654435761u >> 13);
+      REQUIRE(ga3c_frame_preprocess(rgb.data(), g[0], g[1], g[2], 84, 84, plane.data()) == 0);
+    }
+  }
   std::atomic<long> served{0}, trained_rows{0}, produced_rows{0};
   std::vector<std::thread> th;
+  th.emplace_back([&] {     // one predictor runs the native loop
+    ga3c_serve_stats st;
+    std::memset(&st, 0, sizeof st);
+    int rc;
+    while ((rc = ga3c_pq_serve(shm, fake_predict_rows, nullptr, 1, 8, 20, &st)) == GA3C_H_OK) {}
+    REQUIRE(rc == GA3C_H_ECLOSED);
+    REQUIRE(st.largest_batch <= 8);
+    served += st.served;
+  });
   for (int p = 0; p < n_pred; ++p)
     th.emplace_back([&] {
       uint32_t ids[8];
