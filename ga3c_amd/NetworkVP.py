@@ -195,8 +195,11 @@ class Network:
         nat.check(self._lib.ga3c_net_unregister_host(self._h), "ga3c_net_unregister_host")
 
     # ---- frame front-end on the device (Environment.py:52-74; include/ga3c_abi.h: ga3c_net_frames_*) ------------
-    def frames_config(self, max_agents, height=210, width=160, channels=3):
-        nat.check(self._lib.ga3c_net_frames_config(self._h, max_agents, height, width, channels), "ga3c_net_frames_config")
+    def frames_config(self, max_agents, height=210, width=160, channels=3, history=0):
+        """history > 0: the device also keeps each agent's last `history` planes, from which train_frames re-assembles
+        training rows."""
+        nat.check(self._lib.ga3c_net_frames_config(self._h, max_agents, height, width, channels, history),
+                  "ga3c_net_frames_config")
         self._frame_shape = (height, width, channels)
 
     def _frames_arg(self, rgb):
@@ -222,8 +225,33 @@ class Network:
         rs = None if reset is None else np.ascontiguousarray(reset, dtype=np.uint8)
         if agents.size != rgb.shape[0] or (rs is not None and rs.size != agents.size):
             raise ValueError("one agent id (and reset flag) per frame")
+        seq = np.empty(agents.size, np.int64)
         nat.check(self._lib.ga3c_net_frames_push(self._h, nat.ptr(rgb, nat.u8p), nat.ptr(agents, nat.i32p),
-                                                 None if rs is None else nat.ptr(rs, nat.u8p), agents.size), "ga3c_net_frames_push")
+                                                 None if rs is None else nat.ptr(rs, nat.u8p), agents.size,
+                                                 nat.ptr(seq, nat.i64p)), "ga3c_net_frames_push")
+        return seq
+
+    def push_frame_offsets(self, offsets, agents, reset=None):
+        """push_frames for frames lying in the registered transport (byte offsets), e.g. the agents' own slots."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        rs = None if reset is None else np.ascontiguousarray(reset, dtype=np.uint8)
+        seq = np.empty(agents.size, np.int64)
+        nat.check(self._lib.ga3c_net_frames_push_offsets(self._h, nat.ptr(offsets, nat.i64p), nat.ptr(agents, nat.i32p),
+                                                         None if rs is None else nat.ptr(rs, nat.u8p), agents.size,
+                                                         nat.ptr(seq, nat.i64p)), "ga3c_net_frames_push_offsets")
+        return seq
+
+    def train_frames(self, agents, seqs, y_r, a):
+        """One training step on rows named by (agent, plane sequence number) -- see ga3c_net_train_frames."""
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        seqs = np.ascontiguousarray(seqs, dtype=np.int64)
+        y, a = nat.as_f32(y_r), nat.as_f32(a)
+        losses = np.empty(3, dtype=np.float32)
+        nat.check(self._lib.ga3c_net_train_frames(self._h, nat.ptr(agents, nat.i32p), nat.ptr(seqs, nat.i64p), nat.ptr(y),
+                                                  nat.ptr(a), agents.size, float(self.learning_rate), float(self.beta),
+                                                  nat.ptr(losses)), "ga3c_net_train_frames")
+        self.last_losses = losses
 
     def frame_state(self, agent):
         """(uint8 [84,84,4] state or None while the queue holds fewer than 4 planes, queue depth) -- _get_current_state."""

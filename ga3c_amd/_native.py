@@ -62,9 +62,11 @@ HIP_SIGNATURES = {
     "ga3c_net_predict_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, f32p, f32p, f32p]),
     "ga3c_net_train_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, f32p, f32p, C.c_int32, C.c_float,
                                         C.c_float, f32p]),
-    "ga3c_net_frames_config": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "ga3c_net_frames_config": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "ga3c_net_frames_preprocess": (C.c_int, [C.c_void_p, u8p, C.c_int32, u8p]),
-    "ga3c_net_frames_push": (C.c_int, [C.c_void_p, u8p, i32p, u8p, C.c_int32]),
+    "ga3c_net_frames_push": (C.c_int, [C.c_void_p, u8p, i32p, u8p, C.c_int32, i64p]),
+    "ga3c_net_frames_push_offsets": (C.c_int, [C.c_void_p, i64p, i32p, u8p, C.c_int32, i64p]),
+    "ga3c_net_train_frames": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_frames_state": (C.c_int, [C.c_void_p, C.c_int32, u8p, i32p]),
     "ga3c_net_predict_frames": (C.c_int, [C.c_void_p, i32p, C.c_int32, f32p, f32p, f32p]),
     "ga3c_net_frames_upload": (C.c_int, [C.c_void_p, u8p, C.c_int32]),

@@ -116,6 +116,11 @@ struct Frames {
   uint8_t* h_planes = nullptr;         // pinned
   int32_t* h_agents = nullptr;         // pinned, read by the kernel in place
   uint8_t* h_reset = nullptr;          // pinned
+  int64_t* h_src = nullptr;            // pinned: per-frame source offsets (frames_push_offsets)
+  int32_t* h_slot = nullptr;           // pinned: history slot of each pushed plane
+  int hist = 0;                        // planes of history kept per agent (0: none)
+  uint8_t* ring = nullptr;             // [maxA][hist][84*84]
+  std::vector<int64_t> pushed;         // planes pushed per agent so far = sequence number of the next plane
   std::vector<int> filled;             // host mirror of each queue's depth (0..4)
   hipStream_t st = nullptr;
   std::mutex mu;
@@ -481,6 +486,10 @@ void free_frames(Frames& f) {
   if (f.h_planes) (void)hipHostFree(f.h_planes);
   if (f.h_agents) (void)hipHostFree(f.h_agents);
   if (f.h_reset) (void)hipHostFree(f.h_reset);
+  if (f.h_src) (void)hipHostFree(f.h_src);
+  if (f.h_slot) (void)hipHostFree(f.h_slot);
+  if (f.ring) (void)hipFree(f.ring);
+  f.h_src = nullptr; f.h_slot = nullptr; f.ring = nullptr; f.hist = 0;
   if (f.st) (void)hipStreamDestroy(f.st);
   f.d_tab = nullptr; f.stacks = nullptr; f.d_rgb = f.h_rgb = f.d_planes = f.h_planes = f.h_reset = nullptr;
   f.h_agents = nullptr; f.st = nullptr; f.on = false;
@@ -505,10 +514,11 @@ const uint8_t* device_visible(ga3c_net* net, const void* p, size_t bytes) {
 
 // one launch of the front-end over n frames; agents/reset/planes may be null (see FrameArgs)
 int launch_frames(ga3c_net* net, const uint8_t* rgb_dev, const int32_t* agents, const uint8_t* reset, uint8_t* planes,
-                  int n) {
+                  int n, const int64_t* src_off = nullptr) {
   Frames& f = net->fr;
   FrameArgs a;
   a.rgb = rgb_dev; a.agents = agents; a.reset = reset; a.planes = planes; a.stacks = f.stacks;
+  a.src_off = src_off; a.ring = agents ? f.ring : nullptr; a.ring_slot = f.h_slot; a.hist = f.hist;
   a.hb = f.hb; a.hk = f.hk; a.vb = f.vb; a.vk = f.vk;
   a.H = f.H; a.W = f.W; a.C = f.C; a.OH = IMG; a.OW = IMG; a.hks = f.hks; a.vks = f.vks;
   if (reinterpret_cast<uintptr_t>(rgb_dev) & 3) return fail(GA3C_EINVAL, "frames: the frame buffer must be 4-byte aligned");
@@ -959,10 +969,12 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
 }
 
 // ---- frame front-end ------------------------------------------------------------------------------------------
-int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels) {
+int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels,
+                           int32_t history) {
   if (!net) return fail(GA3C_EINVAL, "null argument");
   if (max_agents < 1 || height < 1 || width < 1 || (channels != 3 && channels != 4))
     return fail(GA3C_EINVAL, "frames: need max_agents >= 1, a positive frame size and 3 or 4 channels");
+  if (history != 0 && history < 2 * CIN) return fail(GA3C_EINVAL, "frames: a plane history holds at least %d planes", 2 * CIN);
   HIPCHK(hipSetDevice(net->cfg.device));
   Frames& f = net->fr;
   drop_all_graphs(net);
@@ -997,8 +1009,13 @@ int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, in
   HIPCHK(hipHostMalloc((void**)&f.h_planes, (size_t)max_agents * IMG * IMG, hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&f.h_agents, (size_t)max_agents * sizeof(int32_t), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&f.h_reset, (size_t)max_agents, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&f.h_src, (size_t)max_agents * sizeof(int64_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&f.h_slot, (size_t)max_agents * sizeof(int32_t), hipHostMallocDefault));
+  f.hist = history;
+  if (history) HIPCHK(hipMalloc((void**)&f.ring, (size_t)max_agents * history * IMG * IMG));
   HIPCHK(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
   f.filled.assign((size_t)max_agents, 0);
+  f.pushed.assign((size_t)max_agents, 0);
   f.on = true;
   return GA3C_OK;
 }
@@ -1026,13 +1043,11 @@ int ga3c_net_frames_preprocess(ga3c_net* net, const uint8_t* rgb, int32_t n, uin
   return GA3C_OK;
 }
 
-int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agents, const uint8_t* reset, int32_t n) {
-  if (!net || !rgb || !agents) return fail(GA3C_EINVAL, "null argument");
+// common part of the two push entry points: validates the agent list, fills the pinned argument arrays, launches,
+// waits, advances the host mirrors; seq_out[i] = sequence number of the plane agent i just got (counts from 0)
+static int frames_push_core(ga3c_net* net, const uint8_t* rgb_dev, const int64_t* src_off, const int32_t* agents,
+                            const uint8_t* reset, int n, int64_t* seq_out) {
   Frames& f = net->fr;
-  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
-  if (n < 1 || n > f.maxA) return fail(GA3C_EINVAL, "frames: %d frames outside [1,%d]", n, f.maxA);
-  HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> g(f.mu);
   std::vector<uint8_t> seen((size_t)f.maxA, 0);
   for (int i = 0; i < n; ++i) {
     if (agents[i] < 0 || agents[i] >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agents[i], f.maxA);
@@ -1040,14 +1055,44 @@ int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agent
     seen[agents[i]] = 1;
     f.h_agents[i] = agents[i];
     f.h_reset[i] = reset ? reset[i] : 0;
+    f.h_slot[i] = f.hist ? (int32_t)(f.pushed[agents[i]] % f.hist) : 0;
+    if (src_off) f.h_src[i] = src_off[i];
   }
-  CHK(launch_frames(net, frames_source(net, rgb, n), f.h_agents, f.h_reset, nullptr, n));
+  CHK(launch_frames(net, rgb_dev, f.h_agents, f.h_reset, nullptr, n, src_off ? f.h_src : nullptr));
   HIPCHK(hipStreamSynchronize(f.st));
   for (int i = 0; i < n; ++i) {
     int& d = f.filled[agents[i]];
     d = (reset && reset[i]) ? 1 : (d < CIN ? d + 1 : CIN);
+    if (seq_out) seq_out[i] = f.pushed[agents[i]];
+    f.pushed[agents[i]] += 1;
   }
   return GA3C_OK;
+}
+
+int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agents, const uint8_t* reset, int32_t n,
+                         int64_t* seq_out) {
+  if (!net || !rgb || !agents) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (n < 1 || n > f.maxA) return fail(GA3C_EINVAL, "frames: %d frames outside [1,%d]", n, f.maxA);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  return frames_push_core(net, frames_source(net, rgb, n), nullptr, agents, reset, n, seq_out);
+}
+
+int ga3c_net_frames_push_offsets(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint8_t* reset,
+                                 int32_t n, int64_t* seq_out) {
+  if (!net || !offsets || !agents) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
+  if (n < 1 || n > f.maxA) return fail(GA3C_EINVAL, "frames: %d frames outside [1,%d]", n, f.maxA);
+  for (int i = 0; i < n; ++i)
+    if (offsets[i] < 0 || offsets[i] + (int64_t)f.frame_bytes > net->reg_bytes || (offsets[i] & 3))
+      return fail(GA3C_EINVAL, "frame %d: offset %lld outside the registered segment or not 4-byte aligned", i, (long long)offsets[i]);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> g(f.mu);
+  return frames_push_core(net, net->reg_dev, offsets, agents, reset, n, seq_out);
 }
 
 int ga3c_net_frames_state(ga3c_net* net, int32_t agent, uint8_t* state, int32_t* filled) {
@@ -1081,6 +1126,42 @@ int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, flo
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   for (int i = 0; i < n; ++i) L->h_off[i] = (int64_t)agents[i] * XS;
   return finish_predict(net, L, n, STEP_QUEUES, p, v, z);
+}
+
+int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                          int32_t batch, float learning_rate, float beta, float* losses) {
+  if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on || !f.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  {
+    std::lock_guard<std::mutex> g(f.mu);
+    for (int i = 0; i < batch; ++i) {
+      if (agents[i] < 0 || agents[i] >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agents[i], f.maxA);
+      const int64_t n = f.pushed[agents[i]];
+      if (seqs[i] < CIN - 1 || seqs[i] >= n) return fail(GA3C_EINVAL, "row %d: agent %d has no state at plane %lld", i, agents[i], (long long)seqs[i]);
+      if (n - (seqs[i] - (CIN - 1)) > f.hist)
+        return fail(GA3C_ESTATE, "row %d: plane %lld of agent %d has left the %d-plane history", i, (long long)(seqs[i] - (CIN - 1)), agents[i], f.hist);
+    }
+  }
+  TrainLane* tp = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
+  TrainLane& t = *tp;
+  // the row descriptors ride in the lane's pinned offset array: seqs first, agent ids behind them
+  int64_t* h_seq = t.h_off;
+  int32_t* h_ag = reinterpret_cast<int32_t*>(t.h_in);
+  for (int i = 0; i < batch; ++i) { h_seq[i] = seqs[i]; h_ag[i] = agents[i]; }
+  const int64_t total = (int64_t)batch * (IMG * IMG / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, t.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, t.f.xu8, batch);
+  HIPCHK(hipGetLastError());
+  t.f.x_u8 = true;   // (y_r and a are staged behind the x region of h_in: the ids at its start stay untouched)
+  CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
+  CHK(train_grads(net, t, batch, beta));
+  CHK(train_apply(net, t, learning_rate));
+  return read_losses(net, t, losses);
 }
 
 int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n) {

@@ -25,7 +25,11 @@ constexpr int FE_THREADS = 1024;
 constexpr int FE_PRECISION_BITS = 32 - 8 - 2;
 
 struct FrameArgs {
-  const uint8_t* rgb;        // [n][H][W][C], device-visible
+  const uint8_t* rgb;        // [n][H][W][C], device-visible; or, with src_off, the base the offsets count from
+  const int64_t* src_off;    // [n] byte offset of each frame from rgb (frames scattered over transport slots); may be nullptr
+  uint8_t* ring;             // [max_agents][hist][OH*OW] plane history for training rows; nullptr when hist == 0
+  const int32_t* ring_slot;  // [n] history slot each plane goes to
+  int hist;
   const int32_t* agents;     // [n] queue to push each plane into; nullptr = stateless (planes only)
   const uint8_t* reset;      // [n] non-zero = clear that agent's queue first (Environment.reset); may be nullptr
   uint8_t* planes;           // [n][OH*OW] or nullptr
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   for (int i = tid; i < a.OH * a.vks; i += FE_THREADS) t_vk[i] = a.vk[i];
 
   // ---- pass 1: the frame's bytes -> f64 gray in registers; per-frame min / max
-  const uint8_t* src = a.rgb + (size_t)f * npx * C;
+  const uint8_t* src = a.src_off ? a.rgb + a.src_off[f] : a.rgb + (size_t)f * npx * C;
   double gray[FE_MAXG][4];
   double lo = 1e300, hi = -1e300;
 #pragma unroll
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   const bool clear = a.reset && a.reset[f];
   uint32_t* stack = agent >= 0 ? a.stacks + (size_t)agent * nout : nullptr;
   uint8_t* plane = a.planes ? a.planes + (size_t)f * nout : nullptr;
+  uint8_t* hist = (a.ring && agent >= 0) ? a.ring + ((size_t)agent * a.hist + a.ring_slot[f]) * nout : nullptr;
   for (int i = tid; i < a.OH * groups; i += FE_THREADS) {
     const int yy = i / groups, x0 = (i - yy * groups) * 4;
     const int p0 = yy * a.OW + x0;
@@ -211,7 +216,9 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) v4[q] = (w4 >> (8 * q)) & 255u;
     }
-    if (plane) *reinterpret_cast<uint32_t*>(plane + p0) = v4[0] | (v4[1] << 8) | (v4[2] << 16) | (v4[3] << 24);
+    const uint32_t px4 = v4[0] | (v4[1] << 8) | (v4[2] << 16) | (v4[3] << 24);
+    if (plane) *reinterpret_cast<uint32_t*>(plane + p0) = px4;
+    if (hist) *reinterpret_cast<uint32_t*>(hist + p0) = px4;
     if (stack) {
       s.x = (s.x >> 8) | (v4[0] << 24);
       s.y = (s.y >> 8) | (v4[1] << 24);
@@ -219,6 +226,27 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
       s.w = (s.w >> 8) | (v4[3] << 24);
       *reinterpret_cast<uint4*>(stack + p0) = s;
     }
+  }
+}
+
+// Training rows out of the plane history: x[b] = the [OH,OW,4] uint8 state whose newest plane is history entry
+// seq[b] of agent[b] (planes seq-3 .. seq, oldest first) -- what the agent's queue held right after that push.
+__global__ __launch_bounds__(256) void gather_history_kernel(const uint8_t* __restrict__ ring, const int32_t* __restrict__ agents,
+                                                             const int64_t* __restrict__ seqs, int hist, int nout,
+                                                             uint8_t* __restrict__ x, int B) {
+  const int groups = nout / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)B * groups; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / groups), g = (int)(i - (int64_t)b * groups);
+    const uint8_t* base = ring + (size_t)agents[b] * hist * nout;
+    uint32_t w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = *reinterpret_cast<const uint32_t*>(base + (size_t)((seqs[b] - 3 + c) % hist) * nout + 4 * g);
+    uint4 o;   // pixel q of the group: bytes (plane0, plane1, plane2, plane3)
+    o.x = (w[0] & 255u) | ((w[1] & 255u) << 8) | ((w[2] & 255u) << 16) | ((w[3] & 255u) << 24);
+    o.y = ((w[0] >> 8) & 255u) | (((w[1] >> 8) & 255u) << 8) | (((w[2] >> 8) & 255u) << 16) | (((w[3] >> 8) & 255u) << 24);
+    o.z = ((w[0] >> 16) & 255u) | (((w[1] >> 16) & 255u) << 8) | (((w[2] >> 16) & 255u) << 16) | (((w[3] >> 16) & 255u) << 24);
+    o.w = (w[0] >> 24) | ((w[1] >> 24) << 8) | ((w[2] >> 24) << 16) | ((w[3] >> 24) << 24);
+    *reinterpret_cast<uint4*>(x + ((size_t)b * nout + 4 * g) * 4) = o;
   }
 }
 

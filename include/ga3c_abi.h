@@ -139,16 +139,29 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
  * RGB frame and the [84,84,4] state never leaves HBM.  The arithmetic is the reference's, bit for bit (see
  * include/ga3c_host.h: ga3c_frame_preprocess, and oracle/frame_frontend.py): f64 gray, per-frame min/max bytescale,
  * Pillow's BILINEAR resize to 84x84.
- *   frames_config     height x width x channels (3 or 4) of the frames to come; one queue per agent in [0,max_agents)
+ *   frames_config     height x width x channels (3 or 4) of the frames to come; one queue per agent in [0,max_agents);
+ *                     history > 0 also keeps the last `history` planes of every agent in HBM for train_frames
  *   frames_preprocess stateless: n frames -> n uint8 planes [84*84]                 (= Environment._preprocess)
  *   frames_push       n frames into the queues of n DISTINCT agents; reset[i] != 0 clears that queue first
- *                     (Environment.reset, :86-90)                                    (= _update_frame_q)
+ *                     (Environment.reset, :86-90)                                    (= _update_frame_q);
+ *                     seq_out[i] (may be NULL) = sequence number of the plane agent i just got, counting from 0
+ *   frames_push_offsets  the same for frames lying in the registered transport segment, one byte offset each: the
+ *                     predictor hands over what it popped, nothing is copied on the host
+ *   train_frames      one training step whose row i is the state agent[i]'s queue held right after its plane seq[i]
+ *                     was pushed (planes seq-3 .. seq), re-assembled from the plane history -- rollouts then carry
+ *                     (agent, seq, return, action) instead of 28,224-byte states (ProcessAgent.py:175 / ThreadTrainer.py:49-59)
  *   frames_state      one agent's uint8 [84,84,4] state and queue depth; depth < 4 means "no state yet" (:64-65)
  *   predict_frames    forward pass on the queued states of `agents` (every queue must be full)
  * rgb may be pageable, pinned, device memory or lie in the registered transport segment (read in place then). */
-int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels);
+int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels,
+                           int32_t history);
 int ga3c_net_frames_preprocess(ga3c_net* net, const uint8_t* rgb, int32_t n, uint8_t* planes);
-int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agents, const uint8_t* reset, int32_t n);
+int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agents, const uint8_t* reset, int32_t n,
+                         int64_t* seq_out);
+int ga3c_net_frames_push_offsets(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint8_t* reset,
+                                 int32_t n, int64_t* seq_out);
+int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                          int32_t batch, float learning_rate, float beta, float* losses);
 int ga3c_net_frames_state(ga3c_net* net, int32_t agent, uint8_t* state, int32_t* filled);
 int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, float* p, float* v, float* z);
 /* bench helpers: n frames resident in HBM, then `iters` pushes of them timed with events on the frames stream */

@@ -137,3 +137,67 @@ def test_frames_need_config(net):
             fresh.frames_config(4, 210, 160, 2)
     finally:
         fresh.close()
+
+
+def test_training_rows_from_the_plane_history(net):
+    """Rollouts as (agent, plane sequence number): train_frames re-assembles each row's [84,84,4] state from the
+    device-side plane history; the step must equal, bit for bit, a train() on the states the oracle's frame queues held."""
+    import Transport as tp
+    from NetworkVP import Network
+    rng = np.random.default_rng(21)
+    n_agents, steps, hist = 5, 14, 12
+    other = Network("gpu:0", "test_frontend_ref", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
+    t = tp.Transport.create(tp.unique_name("t_hist"), 8, 6, 4 * 84 * 84 * 4, 2, 6)     # slots hold one raw frame
+    try:
+        theta = net.get_arena(0)
+        for m in (net, other):
+            m.set_arena(0, theta)
+            m.set_arena(1, np.ones_like(theta))
+            m.learning_rate, m.beta = 3e-4, 0.01
+        net.frames_config(8, 210, 160, 3, history=hist)
+        net.register_transport(t)
+        ids = np.array([6, 2, 0, 7, 3], np.int32)
+        queues = [ff.FrameQueue() for _ in range(n_agents)]
+        states = {}                                                  # (agent, seq) -> state the queue held after that push
+        for step in range(steps):
+            rgb = atari_like(rng, n_agents)
+            reset = np.zeros(n_agents, np.uint8)
+            if step == 0:
+                reset[:] = 1
+            if step == 6:
+                reset[1] = 1
+            if step % 2:                                             # odd steps: frames handed over in the transport slots
+                for k, a in enumerate(ids):
+                    t.state_view(a)[:210 * 160 * 3] = rgb[k].reshape(-1)
+                seq = net.push_frame_offsets(t.state_offsets(ids.astype(np.uint32)), ids, reset)
+            else:
+                seq = net.push_frames(rgb, ids, reset)
+            assert seq.tolist() == [step] * n_agents
+            for k in range(n_agents):
+                if reset[k]:
+                    queues[k].clear()
+                queues[k].push(ff.preprocess_u8(rgb[k]))
+                if queues[k].state_u8() is not None:
+                    states[(int(ids[k]), step)] = queues[k].state_u8()
+        live = [(a, s) for (a, s) in states if steps - (s - 3) <= hist]
+        assert len(live) >= 30 and any(s % hist < 3 for _, s in live)           # rows that wrap around the ring
+        pick = [live[i] for i in rng.permutation(len(live))[:24]]
+        x = np.stack([states[k] for k in pick])
+        y = rng.uniform(-1, 1, len(pick))
+        act = np.eye(6, dtype=np.float32)[rng.integers(0, 6, len(pick))]
+        net.train_frames([a for a, _ in pick], [s for _, s in pick], y, act)
+        other.train(x, y, act, None, None, 0)
+        assert np.array_equal(net.get_arena(0), other.get_arena(0))
+        assert np.array_equal(net.last_losses, other.last_losses)
+        gone = [(a, s) for (a, s) in states if steps - (s - 3) > hist][0]
+        with pytest.raises(RuntimeError, match="has left the"):
+            net.train_frames([gone[0]], [gone[1]], y[:1], act[:1])
+        with pytest.raises(RuntimeError, match="no state at plane"):
+            net.train_frames([int(ids[0])], [2], y[:1], act[:1])
+        with pytest.raises(RuntimeError, match="no state at plane"):
+            net.train_frames([int(ids[0])], [steps], y[:1], act[:1])
+    finally:
+        net.unregister_transport()
+        t.shutdown()
+        t.close()
+        other.close()
