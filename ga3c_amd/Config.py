@@ -81,3 +81,12 @@ class Config:
     ZERO_COPY = True                    # GPU gathers states straight from the registered shm transport
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often
     NATIVE_PREDICTOR = True             # ThreadPredictor's loop in native code (ga3c_pq_serve) when ZERO_COPY is on
+    FRAME_SOURCE = 'planes'             # 'planes': synthetic 84x84 uint8 planes; 'rgb': synthetic
+                                        # emulator frames FRAME_HEIGHT x FRAME_WIDTH x 3 that go through the reference's
+                                        # front-end (Environment.py:52-74: gray, bytescale, bilinear resize, frame queue)
+    FRONTEND = 'host'                   # where that front-end runs for 'rgb' frames: 'host' = in the agent process
+                                        # (ga3c_frame_preprocess), states shipped as before; 'device' = the agent ships
+                                        # the raw frame, planes / frame queues / training rows stay in HBM
+    FRAME_HEIGHT = 210
+    FRAME_WIDTH = 160
+    FRAME_HISTORY = 0                   # planes of history per agent on the device; 0 = derived from the queue bounds

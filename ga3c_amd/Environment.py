@@ -25,7 +25,17 @@ def u8_to_f32(frames):
 
 
 class Environment:
+    """Config.FRAME_SOURCE = 'rgb' swaps the 84x84 plane source for a stand-in emulator: every episode draws one random
+    FRAME_HEIGHT x FRAME_WIDTH x 3 background and every step moves an 8x8 sprite of a fresh colour over it and redraws
+    one row of noise -- cheap, deterministic per seed, and enough structure for the contrast stretch and the resize to
+    matter.  FRONTEND = 'host' then runs the reference's _preprocess here (ga3c_frame_preprocess); FRONTEND = 'device'
+    only exposes the raw frame (.frame) and the number of frames since reset (.frames_queued): the state lives in HBM."""
+
     def __init__(self, agent_id=0):
+        self.rgb = Config.FRAME_SOURCE == 'rgb'
+        self.on_device = self.rgb and Config.FRONTEND == 'device'
+        self.frame = None
+        self.frames_queued = 0
         self.nb_frames = Config.STACKED_FRAMES
         self.rng = np.random.Generator(np.random.PCG64(Config.RANDOM_SEED + int(agent_id)))
         self.num_actions = int(Config.NUM_ACTIONS)
@@ -54,6 +64,7 @@ class Environment:
     def reset(self):
         self.total_reward = 0
         self._t = 0
+        self.frames_queued = 0
         self._filled = 0
         self._stack32 = np.zeros((Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH), np.uint32)
         self._push_frame()
@@ -71,9 +82,33 @@ class Environment:
         return reward, done
 
     # ---- internals
+    def _emulate(self):
+        """The stand-in emulator's next RGB frame."""
+        fh, fw = Config.FRAME_HEIGHT, Config.FRAME_WIDTH
+        if self.frames_queued == 0:
+            self._background = np.frombuffer(self.rng.bytes(fh * fw * 3), np.uint8).reshape(fh, fw, 3)
+        frame = self._background.copy()
+        draw = np.frombuffer(self.rng.bytes(8 + fw * 3), np.uint8)
+        y = int(draw[0]) * (fh - 8) // 255
+        x = int(draw[1]) * (fw - 8) // 255
+        frame[y:y + 8, x:x + 8] = draw[2:5]
+        frame[int(draw[5]) * (fh - 1) // 255] = draw[8:].reshape(fw, 3)
+        return frame
+
     def _push_frame(self):
         h, w = Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH
-        frame = np.frombuffer(self.rng.bytes(h * w), np.uint8).reshape(h, w)
+        if self.rgb:
+            self.frame = self._emulate()
+            self.frames_queued += 1
+            if self.on_device:
+                return
+            import _native as nat
+            frame = np.empty((h, w), np.uint8)
+            fh, fw, fc = self.frame.shape
+            nat.check_host(nat.host_lib().ga3c_frame_preprocess(nat.ptr(self.frame, nat.u8p), fh, fw, fc, h, w,
+                                                                nat.ptr(frame, nat.u8p)), "ga3c_frame_preprocess")
+        else:
+            frame = np.frombuffer(self.rng.bytes(h * w), np.uint8).reshape(h, w)
         self._stack32 = (self._stack32 >> _U8) | (frame.astype(np.uint32) << _U24)
         self._filled = min(self._filled + 1, self.nb_frames)
 

@@ -8,6 +8,11 @@ the shared-memory transport (Transport.py / include/ga3c_host.h):
   rollout cut          :145      on done or time_count == TIME_MAX; last experience re-used (:159)
   run()                :164-178  rollout -> training slot; episode totals -> episode_log_q
 
+With Config.FRAME_SOURCE = 'rgb' and FRONTEND = 'device' the agent never holds a state: it writes the emulator's raw
+frame into its slot, the predictor pushes it into the agent's device-side frame queue and answers with the prediction
+for the state that push completed, and an experience names its state by the sequence number of that plane
+(run_episode_device, _ship; include/ga3c_abi.h: ga3c_net_frames_push_offsets / ga3c_net_train_frames).
+
 The debug prints of :131,133,152 are not reproduced; x2_/done_ stay in
 convert_data's signature but are not transported (Q10).
 """
@@ -43,6 +48,7 @@ class ProcessAgent(MP.Process):
         self.time_count = 0
         self.transport = None
         self.env = None
+        self.planes_pushed = 0          # device front-end: frames handed over so far = sequence number of the next plane
 
     # ---- pieces with the reference's names and semantics ------------------------------------
     @staticmethod
@@ -74,6 +80,20 @@ class ProcessAgent(MP.Process):
         slot = self.transport.state_view(self.id, state.dtype)
         slot[:] = state.reshape(-1)
         self.transport.submit(self.id)
+        while True:
+            rc, p, v = self.transport.wait(self.id, Config.QUEUE_TIMEOUT_MS)
+            if rc == 0:
+                return p, v
+            if rc == tp.CLOSED or self.exit_flag.value:
+                raise SystemExit(0)
+
+    def push_frame(self, frame, flags):
+        """Device front-end: the raw frame goes into this agent's slot; the answer is (p, v) of the state the frame
+        completed (meaningless when flags ask for no prediction)."""
+        n = frame.size
+        self.transport.state_view(self.id)[:n] = frame.reshape(-1)
+        self.transport.submit(self.id, flags)
+        self.planes_pushed += 1
         while True:
             rc, p, v = self.transport.wait(self.id, Config.QUEUE_TIMEOUT_MS)
             if rc == 0:
@@ -123,6 +143,37 @@ class ProcessAgent(MP.Process):
                 reward_sum = 0.0
             self.time_count += 1
 
+    def run_episode_device(self):
+        """run_episode with the frame queue on the device: one round trip per emulator step hands the newest frame over
+        and brings back the prediction for the state it completes (same control flow as ProcessAgent.py:117-162)."""
+        env = self.env
+        env.reset()
+        done = False
+        experiences = []
+        self.time_count = 0
+        reward_sum = 0.0
+        flags = tp.REQ_RESET
+        while not done:
+            full = env.frames_queued >= env.nb_frames
+            prediction, value = self.push_frame(env.frame, flags | (0 if full else tp.REQ_NO_PREDICT))
+            flags = 0
+            if not full:
+                env.step(None)                  # frame queue still filling (ProcessAgent.py:127-129)
+                continue
+            state = self.planes_pushed - 1      # the state is named by its newest plane
+            action = self.select_action(self.actions, prediction)
+            reward, done = env.step(action)
+            reward_sum += reward
+            experiences.append(Experience(state, action, prediction, reward, None, done))
+            if done or self.time_count == Config.TIME_MAX:
+                terminal_reward = (0.0 if done else float(value)) if Config.RETURN_MODE == 'nstep' else reward
+                updated = ProcessAgent._accumulate_rewards(experiences, self.discount_factor, terminal_reward)
+                yield updated, reward_sum
+                self.time_count = 0
+                experiences = [experiences[-1]]
+                reward_sum = 0.0
+            self.time_count += 1
+
     def _ship(self, experiences):
         """Rollout -> one slot of the training queue (stands for training_q.put, ProcessAgent.py:175)."""
         while True:
@@ -134,7 +185,11 @@ class ProcessAgent(MP.Process):
         states, returns, actions = self.transport.rollout_views(slot)
         n = len(experiences)
         for i, e in enumerate(experiences):
-            states[i] = e.state.reshape(-1).view(np.uint8)
+            if self.env.on_device:              # row = (plane sequence number, agent id): the state itself is in HBM
+                states[i, :8].view(np.int64)[0] = e.state
+                states[i, 8:12].view(np.int32)[0] = self.id
+            else:
+                states[i] = e.state.reshape(-1).view(np.uint8)
             returns[i] = e.reward               # f64 -> f32 here, as TF's feed does (NetworkVP.py:70,256)
             actions[i] = e.action
         self.transport.commit(slot, n)
@@ -153,7 +208,8 @@ class ProcessAgent(MP.Process):
                 total_reward = 0
                 total_length = 0
                 finished = True
-                for experiences, reward_sum in self.run_episode():
+                episode = self.run_episode_device if self.env.on_device else self.run_episode
+                for experiences, reward_sum in episode():
                     total_reward += reward_sum
                     total_length += len(experiences) + 1        # frame accounting of :174
                     if experiences:

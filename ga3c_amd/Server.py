@@ -36,8 +36,14 @@ class Server:
         self.max_agents = int(max_agents or max(2 * Config.AGENTS, Config.AGENTS + 16))
         n_state = Config.IMAGE_HEIGHT * Config.IMAGE_WIDTH * Config.STACKED_FRAMES
         state_bytes = n_state if Config.STATE_TRANSPORT == 'u8' else 4 * n_state
+        # device-side frame front-end: slots carry the emulator's raw frame, rollout rows only name their state
+        self.device_frontend = Config.FRAME_SOURCE == 'rgb' and Config.FRONTEND == 'device'
+        row_bytes = 0
+        if self.device_frontend:
+            state_bytes = (Config.FRAME_HEIGHT * Config.FRAME_WIDTH * 3 + 15) // 16 * 16
+            row_bytes = 16
         self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
-                                             Config.MAX_QUEUE_SIZE, Config.TIME_MAX + 1)
+                                             Config.MAX_QUEUE_SIZE, Config.TIME_MAX + 1, row_bytes)
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
                                                              self.state_dim)
         if self.dp is not None and hasattr(self.model, "comm_init"):
@@ -46,6 +52,12 @@ class Server:
         self.zero_copy = bool(Config.ZERO_COPY) and hasattr(self.model, "register_transport")
         if self.zero_copy:
             self.model.register_transport(self.transport)
+        if self.device_frontend:
+            if not (self.zero_copy and hasattr(self.model, "frames_config")):
+                raise RuntimeError("FRONTEND = 'device' needs ZERO_COPY and a model with the frames_* entry points")
+            # an agent can be ahead of the trainers by every rollout in flight plus the one it is filling
+            history = Config.FRAME_HISTORY or (Config.MAX_QUEUE_SIZE + 2) * (Config.TIME_MAX + 1) + 8
+            self.model.frames_config(self.max_agents, Config.FRAME_HEIGHT, Config.FRAME_WIDTH, 3, history)
         if Config.LOAD_CHECKPOINT:
             try:
                 self.stats.episode_count.value = self.model.load()
@@ -136,6 +148,18 @@ class Server:
                 return
             self.model.train_offsets(row_offsets, r_, a_)
             self._count_train_step(row_offsets.shape[0], None, r_, a_)
+
+    def train_model_frames(self, agents, seqs, r_, a_, trainer_id):
+        """train_model for rows whose states live in the device-side plane history (FRONTEND = 'device')."""
+        if self.dp is None:
+            self.model.train_frames(agents, seqs, r_, a_)
+            self._count_train_step(agents.shape[0], None, r_, a_)
+            return
+        with self.dp_lock:
+            if not self._may_step():
+                return
+            self.model.train_frames(agents, seqs, r_, a_)
+            self._count_train_step(agents.shape[0], None, r_, a_)
 
     def save_model(self):
         self.model.save(self.stats.episode_count.value)

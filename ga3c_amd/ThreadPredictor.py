@@ -46,8 +46,43 @@ class ThreadPredictor(Thread):
             if rc < 0:
                 break                                   # transport shut down
 
+    def _run_frames(self):
+        """Device front-end: the popped slots hold raw emulator frames.  Push them into the agents' frame queues (the
+        GPU reads them in place), then answer with predictions for the agents whose queue the frame completed."""
+        import Transport as tp
+        t, model = self.transport, self.server.model
+        bmax = Config.PREDICTION_BATCH_SIZE
+        ids = np.zeros(bmax, dtype=np.uint32)
+        p = np.zeros((bmax, t.num_actions), np.float32)
+        v = np.zeros(bmax, np.float32)
+        clock, spent = time.perf_counter, self.seconds
+        while not self.exit_flag:
+            t0 = clock()
+            size = t.pop_batch(ids, Config.QUEUE_TIMEOUT_MS)
+            t1 = clock()
+            spent["pop"] += t1 - t0
+            if size == 0:
+                continue
+            if size < 0:
+                break
+            got = ids[:size]
+            flags = t.request_flags(got)
+            model.push_frame_offsets(t.state_offsets(got), got, (flags & tp.REQ_RESET) != 0)
+            want = np.nonzero((flags & tp.REQ_NO_PREDICT) == 0)[0]
+            if want.size:
+                pw, vw = model.predict_frames(got[want])
+                p[want], v[want] = pw, vw
+            t2 = clock()
+            t.respond(ids, size, p, v)
+            spent["predict"] += t2 - t1
+            spent["respond"] += clock() - t2
+            self.batches += 1
+            self.served += int(want.size)
+
     def run(self):
         t = self.transport
+        if getattr(self.server, "device_frontend", False):
+            return self._run_frames()
         entry = getattr(self.server.model, "gather_entry", None)
         if entry and getattr(self.server, "zero_copy", False) and getattr(Config, "NATIVE_PREDICTOR", True):
             return self._run_native(*entry())

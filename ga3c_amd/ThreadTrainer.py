@@ -29,8 +29,11 @@ class ThreadTrainer(Thread):
         alloc = getattr(self.server.model, "pinned_array", None)
         shape = (cap, t.state_bytes)
         zero_copy = getattr(self.server, "zero_copy", False)
+        on_device = getattr(self.server, "device_frontend", False)     # rows name states kept in HBM: (plane seq, agent)
+        seq_stage = np.zeros(cap, np.int64)
+        agent_stage = np.zeros(cap, np.int32)
         x_stage = None
-        if not zero_copy:
+        if not zero_copy and not on_device:
             x_stage = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
         off_stage = np.zeros(cap, np.int64)
         r_stage = np.zeros(cap, np.float32)
@@ -49,7 +52,11 @@ class ThreadTrainer(Thread):
                 states, returns, actions = t.rollout_views(slot)
                 r_stage[batch_size:batch_size + rows] = returns[:rows]
                 a_stage[batch_size:batch_size + rows] = actions[:rows]
-                if zero_copy:
+                if on_device:
+                    seq_stage[batch_size:batch_size + rows] = states[:rows, :8].view(np.int64).ravel()
+                    agent_stage[batch_size:batch_size + rows] = states[:rows, 8:12].view(np.int32).ravel()
+                    t.release(slot)
+                elif zero_copy:
                     off_stage[batch_size:batch_size + rows] = t.rollout_row_offsets(slot, rows)
                     held.append(slot)
                 else:
@@ -57,7 +64,10 @@ class ThreadTrainer(Thread):
                     t.release(slot)
                 batch_size += rows
             if batch_size and Config.TRAIN_MODELS and not self.exit_flag:
-                if zero_copy:
+                if on_device:
+                    self.server.train_model_frames(agent_stage[:batch_size], seq_stage[:batch_size], r_stage[:batch_size],
+                                                   eye[a_stage[:batch_size]], self.id)
+                elif zero_copy:
                     self.server.train_model_rows(off_stage[:batch_size], r_stage[:batch_size],
                                                  eye[a_stage[:batch_size]], self.id)
                 else:

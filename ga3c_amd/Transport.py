@@ -13,6 +13,7 @@ import numpy as np
 import _native as nat
 
 TIMEOUT, CLOSED = -3, -4
+REQ_RESET, REQ_NO_PREDICT = 1, 2          # request flags (include/ga3c_host.h: GA3C_REQ_*)
 
 
 class Transport:
@@ -24,6 +25,7 @@ class Transport:
         nat.check_host(self._lib.ga3c_shm_get_config(self._h, C.byref(cfg)))
         self.max_agents, self.num_actions = cfg.max_agents, cfg.num_actions
         self.state_bytes, self.train_slots, self.train_rows = cfg.state_bytes, cfg.train_slots, cfg.train_rows
+        self.row_bytes = cfg.rollout_row_bytes or cfg.state_bytes      # bytes of one rollout row
         self.nbytes = self._lib.ga3c_shm_bytes(self._h)
         self.base = self._lib.ga3c_shm_base(self._h)
         self._raw = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.base), dtype=np.uint8)
@@ -37,8 +39,8 @@ class Transport:
 
     # ---- lifecycle
     @classmethod
-    def create(cls, name, max_agents, num_actions, state_bytes, train_slots, train_rows):
-        cfg = nat.ShmConfig(max_agents, num_actions, state_bytes, train_slots, train_rows)
+    def create(cls, name, max_agents, num_actions, state_bytes, train_slots, train_rows, rollout_row_bytes=0):
+        cfg = nat.ShmConfig(max_agents, num_actions, state_bytes, train_slots, train_rows, rollout_row_bytes)
         h = C.c_void_p()
         nat.check_host(nat.host_lib().ga3c_shm_create(name.encode(), C.byref(cfg), C.byref(h)), "ga3c_shm_create")
         t = cls(h, True)
@@ -66,8 +68,14 @@ class Transport:
     def state_view(self, agent, dtype=np.uint8):
         return self.agent_states[agent].view(dtype)
 
-    def submit(self, agent):
-        return nat.check_host(self._lib.ga3c_pq_submit(self._h, agent), "ga3c_pq_submit")
+    def submit(self, agent, flags=0):
+        return nat.check_host(self._lib.ga3c_pq_submit_flags(self._h, agent, flags), "ga3c_pq_submit_flags")
+
+    def request_flags(self, ids):
+        out = np.empty(ids.size, np.uint32)
+        nat.check_host(self._lib.ga3c_pq_request_flags(self._h, nat.ptr(ids, nat.u32p), ids.size, nat.ptr(out, nat.u32p)),
+                       "ga3c_pq_request_flags")
+        return out
 
     def wait(self, agent, timeout_ms=-1):
         p = np.empty(self.num_actions, np.float32)
@@ -93,7 +101,7 @@ class Transport:
     # ---- training queue
     def rollout_views(self, slot):
         base = self._ro_off0 + slot * self._ro_stride
-        states = self._raw[base: base + self.train_rows * self.state_bytes].reshape(self.train_rows, self.state_bytes)
+        states = self._raw[base: base + self.train_rows * self.row_bytes].reshape(self.train_rows, self.row_bytes)
         rp = self._lib.ga3c_tq_returns(self._h, slot)
         ap = self._lib.ga3c_tq_actions(self._h, slot)
         returns = np.frombuffer((C.c_float * self.train_rows).from_address(rp), dtype=np.float32)
@@ -120,7 +128,7 @@ class Transport:
         return self.state_off0 + ids.astype(np.int64) * self.agent_stride
 
     def rollout_row_offsets(self, slot, rows):
-        return self._ro_off0 + slot * self._ro_stride + np.arange(rows, dtype=np.int64) * self.state_bytes
+        return self._ro_off0 + slot * self._ro_stride + np.arange(rows, dtype=np.int64) * self.row_bytes
 
     def ready_count(self):
         return self._lib.ga3c_tq_ready_count(self._h)

@@ -33,7 +33,8 @@ class NetConfig(C.Structure):
 
 class ShmConfig(C.Structure):
     _fields_ = [("max_agents", C.c_int32), ("num_actions", C.c_int32), ("state_bytes", C.c_int32),
-                ("train_slots", C.c_int32), ("train_rows", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("train_slots", C.c_int32), ("train_rows", C.c_int32), ("rollout_row_bytes", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class ServeStats(C.Structure):     # include/ga3c_host.h: ga3c_serve_stats
@@ -105,6 +106,8 @@ HOST_SIGNATURES = {
     "ga3c_shm_rollout_stride": (C.c_int64, [C.c_void_p]),
     "ga3c_pq_state_ptr": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "ga3c_pq_submit": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ga3c_pq_submit_flags": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
+    "ga3c_pq_request_flags": (C.c_int, [C.c_void_p, u32p, C.c_int32, u32p]),
     "ga3c_pq_wait": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32]),
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),

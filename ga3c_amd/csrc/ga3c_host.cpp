@@ -169,7 +169,8 @@ struct AgentMeta {   // lives right behind each agent's state bytes
   float v;
   uint32_t req_seq;                  // written by the agent only
   std::atomic<uint32_t> resp_seq;    // futex word: predictor -> agent
-  uint32_t pad[61];
+  uint32_t req_flags;                // written by the agent before it submits (GA3C_REQ_*), read by the predictor
+  uint32_t pad[60];
 };
 static_assert(sizeof(AgentMeta) == 512, "AgentMeta must stay 512 bytes");
 
@@ -333,8 +334,9 @@ int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out
   if (!name || !cfg || !out) return fail(GA3C_H_EINVAL, "null argument");
   if (cfg->max_agents < 1 || cfg->max_agents > 65536 || cfg->num_actions < 1 || cfg->num_actions > MAXA ||
       cfg->state_bytes < 16 || cfg->state_bytes % 16 != 0 || cfg->train_slots < 1 || cfg->train_slots > 65536 ||
-      cfg->train_rows < 1)
+      cfg->train_rows < 1 || cfg->rollout_row_bytes < 0 || cfg->rollout_row_bytes % 16 != 0)
     return fail(GA3C_H_EINVAL, "bad shm config");
+  const int64_t row_bytes = cfg->rollout_row_bytes ? cfg->rollout_row_bytes : cfg->state_bytes;
   // twice the logical maximum: fewer laps over a cell whose consumer is momentarily descheduled
   const uint32_t req_cap = pow2_at_least(2u * (uint32_t)cfg->max_agents), tr_cap = pow2_at_least(2u * (uint32_t)cfg->train_slots);
   Header lay;
@@ -347,7 +349,7 @@ int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out
   lay.agent_stride = lay.state_span + (int64_t)sizeof(AgentMeta);
   lay.agents_off = off;
   off = round_up(off + lay.agent_stride * cfg->max_agents, 4096);
-  lay.ro_returns_off = round_up((int64_t)cfg->train_rows * cfg->state_bytes, 256);
+  lay.ro_returns_off = round_up((int64_t)cfg->train_rows * row_bytes, 256);
   lay.ro_actions_off = lay.ro_returns_off + round_up((int64_t)cfg->train_rows * 4, 64);
   lay.ro_rows_off = lay.ro_actions_off + round_up((int64_t)cfg->train_rows * 4, 64);
   lay.rollout_stride = round_up(lay.ro_rows_off + 64, 256);
@@ -472,13 +474,25 @@ void* ga3c_pq_state_ptr(ga3c_shm* shm, int32_t agent) {
   return shm->base + shm->hdr()->agents_off + agent * shm->hdr()->agent_stride;
 }
 
-int ga3c_pq_submit(ga3c_shm* shm, int32_t agent) {
+int ga3c_pq_submit(ga3c_shm* shm, int32_t agent) { return ga3c_pq_submit_flags(shm, agent, 0); }
+
+int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags) {
+  if (!shm || !ids || !flags || n < 0) return fail(GA3C_H_EINVAL, "bad argument");
+  for (int i = 0; i < n; ++i) {
+    if (ids[i] >= (uint32_t)shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[i]);
+    flags[i] = shm->meta((int)ids[i])->req_flags;
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags) {
   if (!shm || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad agent id");
   Header* h = shm->hdr();
   if (h->closed.load(std::memory_order_acquire)) return GA3C_H_ECLOSED;
   AgentMeta* m = shm->meta(agent);
   if (m->req_seq != m->resp_seq.load(std::memory_order_acquire))
     return fail(GA3C_H_EINVAL, "agent %d already has a request in flight", agent);
+  m->req_flags = flags;
   m->req_seq += 1;
   std::atomic_thread_fence(std::memory_order_release);   // state bytes before the id becomes visible
   if (!ring_push_wait(shm->base, &h->req, (uint32_t)agent)) {

@@ -67,7 +67,9 @@ typedef struct ga3c_shm_config {
   int32_t state_bytes;   /* 28224 (uint8 frames) or 112896 (f32 states) */
   int32_t train_slots;   /* rollouts in flight (MAX_QUEUE_SIZE) */
   int32_t train_rows;    /* rows per rollout slot (TIME_MAX + 1) */
-  int32_t reserved[3];
+  int32_t rollout_row_bytes; /* bytes per rollout row; 0 = state_bytes (rows carry whole states).  16 when rows only
+                              * name a state kept on the device (agent id + plane sequence, ga3c_net_train_frames) */
+  int32_t reserved[2];
 } ga3c_shm_config;
 
 int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out);  /* server, before agents start */
@@ -85,6 +87,13 @@ int64_t ga3c_shm_rollout_stride(ga3c_shm* shm);
 /* agent side of predict (ProcessAgent.py:102-107) */
 void* ga3c_pq_state_ptr(ga3c_shm* shm, int32_t agent);
 int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
+/* The same with request flags for the predictor (device-side frame front-end: the slot then holds the emulator's raw
+ * frame, Environment.py:76-93): RESET = the episode just started, clear the agent's frame queue first
+ * (Environment.reset); NO_PREDICT = push the frame only, the queue is not full yet (ProcessAgent.py:127-129). */
+#define GA3C_REQ_RESET 1u
+#define GA3C_REQ_NO_PREDICT 2u
+int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags);
+int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags);   /* predictor side */
 int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
 /* predictor side (ThreadPredictor.py:50-55,61-63): block up to timeout for ONE request, then drain
  * without waiting up to max_ids; returns the count (0 on timeout). */

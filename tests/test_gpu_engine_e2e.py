@@ -189,3 +189,34 @@ def test_hogwild_train_lanes():
     finally:
         sync.close()
         hog.close()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("frontend", ["device", "host"])
+def test_engine_on_raw_frames(tmp_path, monkeypatch, frontend):
+    """FRAME_SOURCE = 'rgb': agents produce 210x160x3 emulator frames.  FRONTEND = 'device': they ship the raw frame, the
+    HIP front-end queues planes in HBM, predictions read the queues, rollouts name their states by (agent, plane) and are
+    re-assembled from the plane history.  FRONTEND = 'host': the agent runs ga3c_frame_preprocess and ships states."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=6, PREDICTORS=2, TRAINERS=1, SYNTHETIC_EPISODE_LENGTH=40, TIME_MAX=5, DYNAMIC_SETTINGS=False,
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=11, NUM_ACTIONS=6, PREDICTION_BATCH_SIZE=32,
+                     FRAME_SOURCE='rgb', FRONTEND=frontend).items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    srv = Server(max_agents=8)
+    try:
+        assert srv.device_frontend == (frontend == "device")
+        before = srv.model.get_arena(0)
+        srv.main(max_seconds=5)
+        after = srv.model.get_arena(0)
+        assert srv.predictions_served > 100 and srv.training_step > 5
+        assert srv.model.get_global_step() == srv.training_step
+        assert np.all(np.isfinite(after)) and np.max(np.abs(after - before)) > 1e-5
+        assert all(not th.is_alive() for th in srv.trainers + srv.predictors)
+        if frontend == "device":
+            state, depth = srv.model.frame_state(0)
+            assert depth == 4 and state.shape == (84, 84, 4) and int(state.max()) - int(state.min()) > 50
+    finally:
+        srv.model.close()

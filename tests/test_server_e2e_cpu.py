@@ -73,3 +73,123 @@ def test_status_line_format_is_the_references():
     line = ProcessStats.status_line(35, 30, -20.0, -20.4, 899, 900, 186, 2, 2, 32, 0)
     assert line == ("[Time:       35] [Episode:       30 Score:   -20.0000] [RScore:   -20.4000 RPPS:   899] "
                     "[PPS:   900 TPS:   186] [NT:  2 NP:  2 NA: 32][RSize:        0]")
+
+
+class _DeviceFrontEndStandIn:
+    """Stand-in for the HIP Network in FRONTEND = 'device' mode: frames_* entry points backed by the oracle's front-end,
+    so that the whole raw-frame protocol (agent -> slot -> predictor -> queue; rollouts as (agent, plane)) runs on CPU."""
+
+    def __init__(self, n_act):
+        import frame_frontend as ff
+        self.ff, self.n_act = ff, n_act
+        self.learning_rate = self.beta = 0.0
+        self.transport = None
+        self.queues, self.pushed, self.has_state = {}, {}, set()
+        self.problems, self.train_rows, self.pred_sizes, self.resets = [], [], [], 0
+        self.history = None
+
+    def register_transport(self, transport):
+        self.transport = transport
+
+    def unregister_transport(self):
+        self.transport = None
+
+    def frames_config(self, max_agents, height, width, channels, history=0):
+        self.shape, self.history = (height, width, channels), history
+
+    def push_frame_offsets(self, offsets, agents, reset=None):
+        n = int(np.prod(self.shape))
+        for i, (off, a) in enumerate(zip(offsets, agents)):
+            a = int(a)
+            q = self.queues.setdefault(a, self.ff.FrameQueue())
+            if reset is not None and reset[i]:
+                q.clear()
+                self.resets += 1
+            frame = self.transport._raw[off: off + n].reshape(self.shape)
+            q.push(frame[:84, :84, 0])          # any plane will do here: the arithmetic is held to the oracle on the GPU
+            seq = self.pushed.get(a, 0)
+            self.pushed[a] = seq + 1
+            if q.state_u8() is not None:
+                self.has_state.add((a, seq))
+
+    def predict_frames(self, agents):
+        for a in agents:
+            if self.queues[int(a)].state_u8() is None:
+                self.problems.append("prediction asked for agent %d before its queue was full" % a)
+        self.pred_sizes.append(len(agents))
+        b = len(agents)
+        return np.full((b, self.n_act), 1.0 / self.n_act, np.float32), np.zeros(b, np.float32)
+
+    def train_frames(self, agents, seqs, y_r, a):
+        for ag, s in zip(agents, seqs):
+            if (int(ag), int(s)) not in self.has_state:
+                self.problems.append("row (%d, %d) names no state" % (ag, s))
+            if self.pushed[int(ag)] - (int(s) - 3) > self.history:
+                self.problems.append("row (%d, %d) left the history" % (ag, s))
+        assert a.shape == (len(agents), self.n_act) and y_r.shape == (len(agents),)
+        self.train_rows.append(len(agents))
+
+    def save(self, episode):
+        pass
+
+    def log(self, *a, **k):
+        pass
+
+
+@pytest.mark.timeout(120)
+def test_device_front_end_protocol_on_cpu(tmp_path, monkeypatch):
+    """FRAME_SOURCE = 'rgb', FRONTEND = 'device': agents ship raw frames, the predictor pushes them in order and predicts
+    only on full queues, rollouts arrive as (agent, plane sequence) rows that name existing states."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    keys = ("AGENTS", "PREDICTORS", "TRAINERS", "SYNTHETIC_EPISODE_LENGTH", "TIME_MAX", "DYNAMIC_SETTINGS", "SAVE_MODELS",
+            "TRAINING_MIN_BATCH_SIZE", "NUM_ACTIONS", "FRAME_SOURCE", "FRONTEND")
+    saved = {k: getattr(Config, k) for k in keys}
+    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = 3, 2, 1
+    Config.SYNTHETIC_EPISODE_LENGTH, Config.TIME_MAX = 23, 5
+    Config.DYNAMIC_SETTINGS, Config.SAVE_MODELS = False, False
+    Config.TRAINING_MIN_BATCH_SIZE, Config.NUM_ACTIONS = 11, 6
+    Config.FRAME_SOURCE, Config.FRONTEND = 'rgb', 'device'
+    try:
+        from Server import Server
+        model = _DeviceFrontEndStandIn(6)
+        srv = Server(model=model, max_agents=8)
+        assert srv.device_frontend and srv.transport.row_bytes == 16 and srv.transport.state_bytes >= 210 * 160 * 3
+        assert model.history == (Config.MAX_QUEUE_SIZE + 2) * 6 + 8
+        srv.main(max_seconds=6)
+        assert model.problems == []
+        assert srv.predictions_served > 50 and sum(model.pred_sizes) == srv.predictions_served
+        assert model.train_rows and min(model.train_rows) > 11 and srv.training_step == len(model.train_rows)
+        assert model.resets >= 3                                    # every episode start clears its queue
+        lengths = [int(ln.split(", ")[2]) for ln in open("results.txt").read().strip().splitlines()]
+        assert lengths and set(lengths) == {32}                     # same frame accounting as the state-shipping path
+    finally:
+        for k, v in saved.items():
+            setattr(Config, k, v)
+
+
+def test_rgb_source_with_host_front_end_feeds_reference_planes(monkeypatch):
+    """FRAME_SOURCE = 'rgb', FRONTEND = 'host': Environment runs the reference's _preprocess in the agent; its states must
+    be the oracle's planes of the same emulator frames, stacked oldest first."""
+    import ga3c_amd  # noqa: F401
+    import frame_frontend as ff
+    from Config import Config
+    from Environment import Environment
+    monkeypatch.setattr(Config, "FRAME_SOURCE", "rgb")
+    monkeypatch.setattr(Config, "FRONTEND", "host")
+    monkeypatch.setattr(Config, "SYNTHETIC_EPISODE_LENGTH", 5)
+    env = Environment(1)
+    planes = [ff.preprocess_u8(env.frame)]
+    assert env.frame.shape == (210, 160, 3) and env.current_u8 is None
+    for t in range(1, 7):
+        env.step(0)
+        planes.append(ff.preprocess_u8(env.frame))
+        if t >= 3:
+            assert np.array_equal(env.current_u8, np.stack(planes[-4:], axis=-1))
+    raw = Environment(1)
+    monkeypatch.setattr(Config, "FRONTEND", "device")
+    dev = Environment(1)
+    assert dev.on_device and np.array_equal(dev.frame, raw.frame) and dev.frames_queued == 1
+    dev.step(0)
+    assert dev.current_u8 is None and dev.frames_queued == 2

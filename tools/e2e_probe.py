@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--hogwild", action="store_true")
     ap.add_argument("--python-predictor", action="store_true", help="keep ThreadPredictor's loop in Python")
+    ap.add_argument("--frames", choices=["planes", "rgb-host", "rgb-device"], default="planes",
+                    help="frame source / where the reference's front-end runs (Config.FRAME_SOURCE, Config.FRONTEND)")
     args = ap.parse_args()
 
     import psutil
@@ -44,6 +46,8 @@ def main():
     Config.TRAIN_MODELS = not args.no_train
     Config.HOGWILD = bool(args.hogwild)
     Config.NATIVE_PREDICTOR = not args.python_predictor
+    if args.frames != "planes":
+        Config.FRAME_SOURCE, Config.FRONTEND = "rgb", args.frames.split("-")[1]
     Config.SAVE_MODELS = False
     Config.LOAD_CHECKPOINT = False
     Config.RESULTS_FILENAME = "/tmp/e2e_probe_results.txt"
@@ -88,7 +92,7 @@ def main():
     pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
     print(json.dumps({
         "agents": args.agents, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
-        "hogwild": bool(args.hogwild), "native_predictor": not args.python_predictor, "window_s": round(dt, 2), "host_cores": os.cpu_count(),
+        "hogwild": bool(args.hogwild), "frames": args.frames, "native_predictor": not args.python_predictor, "window_s": round(dt, 2), "host_cores": os.cpu_count(),
         "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
         "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),
         "predictor_us_per_batch": {k: round((b["loop"][k] - a["loop"][k]) / batches * 1e6, 1) for k in b["loop"]},
