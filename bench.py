@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0                                                   # MI355X
 MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
 
 
-def run_engine(model, seconds, agents, B, A):
+def run_engine(model, seconds, agents, B, A, frames="planes"):
     """The whole engine for `seconds`: synthetic agents -> shm transport -> ThreadPredictor / ThreadTrainer -> `model`
     (None = the HIP Network).  Returns rates over the steady window of the run."""
     import threading
@@ -52,6 +52,7 @@ def run_engine(model, seconds, agents, B, A):
     Config.PRINT_STATS_FREQUENCY = 10 ** 9
     Config.RESULTS_FILENAME = os.devnull
     Config.NUM_ACTIONS = A
+    Config.FRAME_SOURCE, Config.FRONTEND = ("planes", "host") if frames == "planes" else ("rgb", frames.split("-")[1])
     real_stdout = sys.stdout
     sys.stdout = sys.stderr
     try:
@@ -373,6 +374,15 @@ def main():
                           note="synthetic Python agents (PCG64 frames) on this box's host cores; predictions served and "
                                "train steps taken by the engine over the steady window of the run (whole_run includes "
                                "forking the agents)")
+        # the same engine fed with raw 210x160x3 emulator frames: the reference's front-end in the agents (host) against the
+        # HIP front-end with device-resident frame queues and (agent, plane) rollouts
+        half = max(4.0, args.e2e_seconds * 0.75)
+        out["e2e"]["raw_frames"] = {
+            mode: {k: r[k] for k in ("predictions_per_sec", "training_steps_per_sec", "mean_predict_batch", "seconds")}
+            for mode, r in ((m, run_engine(None, half, args.e2e_agents, B, A, frames="rgb-" + m)) for m in ("host", "device"))}
+        out["e2e"]["raw_frames"]["note"] = ("synthetic emulator frames; 'host': ga3c_frame_preprocess in every agent process, "
+                                            "states shipped; 'device': raw frames shipped, front-end + frame queues + plane "
+                                            "history on the GPU")
         if cpu_theta is not None:      # the same harness with the oracle's C port as the model: the CPU path beside it
             import ga3c_oracle_cport as oc
             oc.lib().ga3c_oc_set_threads(4)       # 2 predictor + 2 trainer threads call in concurrently: 4 x 4 = the 16-core share

@@ -269,6 +269,23 @@ class Network:
                   "ga3c_net_predict_frames")
         return [p, v]
 
+    def frames_entry(self):
+        """(address of ga3c_net_serve_frames, engine handle): the callback of the native raw-frame predictor loop."""
+        return C.cast(self._lib.ga3c_net_serve_frames, C.c_void_p).value, self._h
+
+    def serve_frames(self, offsets, agents, flags):
+        """push + predict of one popped batch in one GPU round trip (what the native loop calls); rows of requests that
+        asked for no prediction come back as zeros."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        flags = np.ascontiguousarray(flags, dtype=np.uint32)
+        p = np.zeros((agents.size, self.num_actions), dtype=np.float32)
+        v = np.zeros((agents.size,), dtype=np.float32)
+        nat.check(self._lib.ga3c_net_serve_frames(self._h, nat.ptr(offsets, nat.i64p), nat.ptr(agents, nat.i32p),
+                                                  nat.ptr(flags, nat.u32p), agents.size, nat.ptr(p), nat.ptr(v)),
+                  "ga3c_net_serve_frames")
+        return [p, v]
+
     def gather_entry(self):
         """(address of ga3c_net_predict_gather, engine handle, u8 flag): what the native predictor loop
         (ga3c_pq_serve, include/ga3c_host.h) calls for every batch instead of predict_offsets()."""

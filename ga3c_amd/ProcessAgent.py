@@ -79,7 +79,8 @@ class ProcessAgent(MP.Process):
         """state: uint8 [84,84,4] frames (STATE_TRANSPORT='u8') or f32 [84,84,4]."""
         slot = self.transport.state_view(self.id, state.dtype)
         slot[:] = state.reshape(-1)
-        self.transport.submit(self.id)
+        if self.transport.submit(self.id) == tp.CLOSED:     # nothing was queued: waiting would return the previous answer
+            raise SystemExit(0)
         while True:
             rc, p, v = self.transport.wait(self.id, Config.QUEUE_TIMEOUT_MS)
             if rc == 0:
@@ -92,7 +93,8 @@ class ProcessAgent(MP.Process):
         completed (meaningless when flags ask for no prediction)."""
         n = frame.size
         self.transport.state_view(self.id)[:n] = frame.reshape(-1)
-        self.transport.submit(self.id, flags)
+        if self.transport.submit(self.id, flags) == tp.CLOSED:     # nothing was queued (see predict)
+            raise SystemExit(0)
         self.planes_pushed += 1
         while True:
             rc, p, v = self.transport.wait(self.id, Config.QUEUE_TIMEOUT_MS)

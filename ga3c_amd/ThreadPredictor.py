@@ -51,6 +51,18 @@ class ThreadPredictor(Thread):
         GPU reads them in place), then answer with predictions for the agents whose queue the frame completed."""
         import Transport as tp
         t, model = self.transport, self.server.model
+        entry = getattr(model, "frames_entry", None)
+        if entry and getattr(Config, "NATIVE_PREDICTOR", True):     # the same loop in native code, one GPU round trip per batch
+            fn, handle = entry()
+            st = nat.ServeStats()
+            self.native = True
+            while not self.exit_flag:
+                rc = t.serve_frames(fn, handle, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+                self.batches, self.served = st.batches, st.served
+                self.seconds = {"pop": st.ns_pop * 1e-9, "predict": st.ns_predict * 1e-9, "respond": st.ns_respond * 1e-9}
+                if rc < 0:
+                    break
+            return
         bmax = Config.PREDICTION_BATCH_SIZE
         ids = np.zeros(bmax, dtype=np.uint32)
         p = np.zeros((bmax, t.num_actions), np.float32)

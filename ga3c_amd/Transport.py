@@ -98,6 +98,11 @@ class Transport:
         rc = self._lib.ga3c_pq_serve(self._h, entry, net_handle, int(u8), int(max_batch), int(slice_ms), C.addressof(stats))
         return nat.check_host(rc, "ga3c_pq_serve")
 
+    def serve_frames(self, entry, net_handle, max_batch, slice_ms, stats):
+        """One time slice of the native predictor loop for raw-frame requests (ga3c_pq_serve_frames)."""
+        rc = self._lib.ga3c_pq_serve_frames(self._h, entry, net_handle, int(max_batch), int(slice_ms), C.addressof(stats))
+        return nat.check_host(rc, "ga3c_pq_serve_frames")
+
     # ---- training queue
     def rollout_views(self, slot):
         base = self._ro_off0 + slot * self._ro_stride

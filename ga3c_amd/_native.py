@@ -67,6 +67,7 @@ HIP_SIGNATURES = {
     "ga3c_net_frames_preprocess": (C.c_int, [C.c_void_p, u8p, C.c_int32, u8p]),
     "ga3c_net_frames_push": (C.c_int, [C.c_void_p, u8p, i32p, u8p, C.c_int32, i64p]),
     "ga3c_net_frames_push_offsets": (C.c_int, [C.c_void_p, i64p, i32p, u8p, C.c_int32, i64p]),
+    "ga3c_net_serve_frames": (C.c_int, [C.c_void_p, i64p, i32p, u32p, C.c_int32, f32p, f32p]),
     "ga3c_net_train_frames": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_frames_state": (C.c_int, [C.c_void_p, C.c_int32, u8p, i32p]),
     "ga3c_net_predict_frames": (C.c_int, [C.c_void_p, i32p, C.c_int32, f32p, f32p, f32p]),
@@ -112,6 +113,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),
     "ga3c_frame_preprocess": (C.c_int, [u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, u8p]),
+    "ga3c_pq_serve_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_pq_serve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_tq_acquire": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_tq_states": (C.c_void_p, [C.c_void_p, C.c_int32]),

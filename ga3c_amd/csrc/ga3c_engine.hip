@@ -514,16 +514,17 @@ const uint8_t* device_visible(ga3c_net* net, const void* p, size_t bytes) {
 
 // one launch of the front-end over n frames; agents/reset/planes may be null (see FrameArgs)
 int launch_frames(ga3c_net* net, const uint8_t* rgb_dev, const int32_t* agents, const uint8_t* reset, uint8_t* planes,
-                  int n, const int64_t* src_off = nullptr) {
+                  int n, const int64_t* src_off = nullptr, hipStream_t st = nullptr, const int32_t* slots = nullptr) {
   Frames& f = net->fr;
+  if (!st) st = f.st;
   FrameArgs a;
   a.rgb = rgb_dev; a.agents = agents; a.reset = reset; a.planes = planes; a.stacks = f.stacks;
-  a.src_off = src_off; a.ring = agents ? f.ring : nullptr; a.ring_slot = f.h_slot; a.hist = f.hist;
+  a.src_off = src_off; a.ring = agents ? f.ring : nullptr; a.ring_slot = slots ? slots : f.h_slot; a.hist = f.hist;
   a.hb = f.hb; a.hk = f.hk; a.vb = f.vb; a.vk = f.vk;
   a.H = f.H; a.W = f.W; a.C = f.C; a.OH = IMG; a.OW = IMG; a.hks = f.hks; a.vks = f.vks;
   if (reinterpret_cast<uintptr_t>(rgb_dev) & 3) return fail(GA3C_EINVAL, "frames: the frame buffer must be 4-byte aligned");
-  if (f.C == 3) hipLaunchKernelGGL(frame_frontend_kernel<3>, dim3(n), dim3(FE_THREADS), f.lds, f.st, a);
-  else hipLaunchKernelGGL(frame_frontend_kernel<4>, dim3(n), dim3(FE_THREADS), f.lds, f.st, a);
+  if (f.C == 3) hipLaunchKernelGGL(frame_frontend_kernel<3>, dim3(n), dim3(FE_THREADS), f.lds, st, a);
+  else hipLaunchKernelGGL(frame_frontend_kernel<4>, dim3(n), dim3(FE_THREADS), f.lds, st, a);
   HIPCHK(hipGetLastError());
   return GA3C_OK;
 }
@@ -1128,6 +1129,65 @@ int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, flo
   return finish_predict(net, L, n, STEP_QUEUES, p, v, z);
 }
 
+int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
+                          float* p, float* v) {
+  if (!net || !offsets || !agents || !flags || !p || !v) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
+  if (n < 1 || n > f.maxA || n > net->maxB) return fail(GA3C_EINVAL, "frames: %d requests outside [1,%d]", n, f.maxA < net->maxB ? f.maxA : net->maxB);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  Lane* L = take_lane(net);
+  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  // per-call argument arrays, carved out of the lane's (otherwise idle) pinned input staging and read by the kernels in place
+  int32_t* h_ag = reinterpret_cast<int32_t*>(L->h_in);
+  int32_t* h_slot = h_ag + net->maxB;
+  int64_t* h_src = reinterpret_cast<int64_t*>(h_slot + net->maxB);
+  uint8_t* h_reset = reinterpret_cast<uint8_t*>(h_src + net->maxB);
+  int want = 0;
+  {
+    std::lock_guard<std::mutex> g(f.mu);   // host mirrors of the queues; per agent the protocol allows one request in flight
+    std::vector<uint8_t> seen((size_t)f.maxA, 0);
+    for (int i = 0; i < n; ++i) {
+      const int a = agents[i];
+      if (a < 0 || a >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", a, f.maxA);
+      if (seen[a]) return fail(GA3C_EINVAL, "frames: agent %d appears twice in one batch", a);
+      if (offsets[i] < 0 || offsets[i] + (int64_t)f.frame_bytes > net->reg_bytes || (offsets[i] & 3))
+        return fail(GA3C_EINVAL, "frame %d: offset %lld outside the registered segment or not 4-byte aligned", i, (long long)offsets[i]);
+      seen[a] = 1;
+    }
+    for (int i = 0; i < n; ++i) {
+      const int a = agents[i];
+      const bool rs = (flags[i] & 1u) != 0;
+      h_ag[i] = a; h_src[i] = offsets[i]; h_reset[i] = rs ? 1 : 0;
+      h_slot[i] = f.hist ? (int32_t)(f.pushed[a] % f.hist) : 0;
+      f.pushed[a] += 1;
+      int& d = f.filled[a];
+      d = rs ? 1 : (d < CIN ? d + 1 : CIN);
+      if (!(flags[i] & 2u)) {
+        if (d < CIN) return fail(GA3C_ESTATE, "frames: agent %d asks for a prediction with %d of %d frames queued", a, d, CIN);
+        L->h_off[want++] = (int64_t)a * XS;
+      }
+    }
+  }
+  CHK(launch_frames(net, net->reg_dev, h_ag, h_reset, nullptr, n, h_src, L->st, h_slot));   // same stream as the forward pass
+  if (want == 0) {
+    HIPCHK(hipStreamSynchronize(L->st));
+    return GA3C_OK;
+  }
+  const int A = net->A;
+  float* hp = L->h_out;
+  float* hv = hp + (size_t)net->maxB * A;
+  CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
+  HIPCHK(hipStreamSynchronize(L->st));
+  for (int i = 0, k = 0; i < n; ++i) {
+    if (flags[i] & 2u) continue;
+    memcpy(p + (size_t)i * A, hp + (size_t)k * A, (size_t)A * sizeof(float));
+    v[i] = hv[k++];
+  }
+  return GA3C_OK;
+}
+
 int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses) {
   if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
@@ -1140,7 +1200,8 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
     for (int i = 0; i < batch; ++i) {
       if (agents[i] < 0 || agents[i] >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agents[i], f.maxA);
       const int64_t n = f.pushed[agents[i]];
-      if (seqs[i] < CIN - 1 || seqs[i] >= n) return fail(GA3C_EINVAL, "row %d: agent %d has no state at plane %lld", i, agents[i], (long long)seqs[i]);
+      if (seqs[i] < CIN - 1 || seqs[i] >= n)
+        return fail(GA3C_EINVAL, "row %d: agent %d has no state at plane %lld (%lld planes pushed)", i, agents[i], (long long)seqs[i], (long long)n);
       if (n - (seqs[i] - (CIN - 1)) > f.hist)
         return fail(GA3C_ESTATE, "row %d: plane %lld of agent %d has left the %d-plane history", i, (long long)(seqs[i] - (CIN - 1)), agents[i], f.hist);
     }

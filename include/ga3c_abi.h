@@ -160,6 +160,12 @@ int ga3c_net_frames_push(ga3c_net* net, const uint8_t* rgb, const int32_t* agent
                          int64_t* seq_out);
 int ga3c_net_frames_push_offsets(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint8_t* reset,
                                  int32_t n, int64_t* seq_out);
+/* One predictor batch in raw-frame mode, one GPU round trip: the n popped requests' frames (byte offsets into the
+ * registered segment) are pushed into their agents' queues -- flags[i] & 1: clear the queue first, flags[i] & 2: push
+ * only (GA3C_REQ_RESET / GA3C_REQ_NO_PREDICT of include/ga3c_host.h) -- and rows i of p / v are filled for every request
+ * that asked for a prediction.  This is the callback of the native predictor loop ga3c_pq_serve_frames. */
+int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
+                          float* p, float* v);
 int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses);
 int ga3c_net_frames_state(ga3c_net* net, int32_t agent, uint8_t* state, int32_t* filled);

@@ -115,6 +115,13 @@ typedef struct ga3c_serve_stats {
 } ga3c_serve_stats;
 int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
                   int32_t slice_ms, ga3c_serve_stats* stats);
+/* The same loop for raw-frame requests (ga3c_pq_submit_flags): `serve` has the signature of ga3c_net_serve_frames
+ * (include/ga3c_abi.h) and gets the popped slots' offsets, agent ids and request flags; stats->served counts the
+ * predictions made (requests without GA3C_REQ_NO_PREDICT). */
+typedef int (*ga3c_serve_frames_fn)(void* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags,
+                                    int32_t n, float* p, float* v);
+int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, int32_t max_batch, int32_t slice_ms,
+                         ga3c_serve_stats* stats);
 
 /* training queue: agent side (ProcessAgent.py:175), trainer side (ThreadTrainer.py:49-59) */
 int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms);                 /* -> free slot id */

@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(180)
+@pytest.mark.filterwarnings("error::pytest.PytestUnhandledThreadExceptionWarning")
 @pytest.mark.parametrize("zero_copy", [True, False])
 def test_engine_trains_on_gpu(tmp_path, monkeypatch, zero_copy):
     import ga3c_amd  # noqa: F401
@@ -192,6 +193,7 @@ def test_hogwild_train_lanes():
 
 
 @pytest.mark.timeout(180)
+@pytest.mark.filterwarnings("error::pytest.PytestUnhandledThreadExceptionWarning")     # a dying batcher thread fails the test
 @pytest.mark.parametrize("frontend", ["device", "host"])
 def test_engine_on_raw_frames(tmp_path, monkeypatch, frontend):
     """FRAME_SOURCE = 'rgb': agents produce 210x160x3 emulator frames.  FRONTEND = 'device': they ship the raw frame, the
@@ -216,7 +218,8 @@ def test_engine_on_raw_frames(tmp_path, monkeypatch, frontend):
         assert np.all(np.isfinite(after)) and np.max(np.abs(after - before)) > 1e-5
         assert all(not th.is_alive() for th in srv.trainers + srv.predictors)
         if frontend == "device":
-            state, depth = srv.model.frame_state(0)
-            assert depth == 4 and state.shape == (84, 84, 4) and int(state.max()) - int(state.min()) > 50
+            seen = [srv.model.frame_state(a) for a in range(6)]       # an agent may just have started an episode
+            assert all(1 <= depth <= 4 for _, depth in seen) and any(depth == 4 for _, depth in seen)
+            assert all(s.shape == (84, 84, 4) and int(s.max()) - int(s.min()) > 50 for s, _ in seen if s is not None)
     finally:
         srv.model.close()

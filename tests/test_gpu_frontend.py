@@ -201,3 +201,54 @@ def test_training_rows_from_the_plane_history(net):
         t.shutdown()
         t.close()
         other.close()
+
+
+def test_serve_frames_is_push_plus_predict_in_one_round_trip(net):
+    """ga3c_net_serve_frames (the native raw-frame predictor loop's callback) against the two-call path."""
+    import Transport as tp
+    from NetworkVP import Network
+    rng = np.random.default_rng(33)
+    other = Network("gpu:0", "test_frontend_two_call", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
+    t = tp.Transport.create(tp.unique_name("t_srvfr"), 8, 6, 4 * 84 * 84 * 4, 2, 6)
+    t2 = tp.Transport.create(tp.unique_name("t_srvfr2"), 8, 6, 4 * 84 * 84 * 4, 2, 6)   # one segment per engine
+    try:
+        other.set_arena(0, net.get_arena(0))
+        ids = np.array([1, 4, 6, 3], np.int32)
+        for m, seg in ((net, t), (other, t2)):
+            m.frames_config(8, 210, 160, 3, history=16)
+            m.register_transport(seg)
+        offs = t.state_offsets(ids.astype(np.uint32))
+        assert np.array_equal(offs, t2.state_offsets(ids.astype(np.uint32)))
+        for step in range(7):
+            rgb = atari_like(rng, 4)
+            for k, a in enumerate(ids):
+                t.state_view(a)[:210 * 160 * 3] = rgb[k].reshape(-1)
+                t2.state_view(a)[:210 * 160 * 3] = rgb[k].reshape(-1)
+            flags = np.zeros(4, np.uint32)
+            if step == 0:
+                flags |= tp.REQ_RESET
+            if step == 4:
+                flags[2] |= tp.REQ_RESET                              # agent 6 starts a new episode
+            depth_after = np.array([min(step + 1, 4)] * 4)
+            depth_after[2] = min(step + 1, 4) if step < 4 else min(step - 3, 4)
+            flags[depth_after < 4] |= tp.REQ_NO_PREDICT
+            p, v = net.serve_frames(offs, ids, flags)
+            other.push_frame_offsets(offs, ids, (flags & tp.REQ_RESET) != 0)
+            want = np.nonzero((flags & tp.REQ_NO_PREDICT) == 0)[0]
+            if want.size:
+                p2, v2 = other.predict_frames(ids[want])
+                assert np.array_equal(p[want], p2) and np.array_equal(v[want], v2)
+            assert not p[(flags & tp.REQ_NO_PREDICT) != 0].any()
+            for a in ids:
+                s1, d1 = net.frame_state(a)
+                s2, d2 = other.frame_state(a)
+                assert d1 == d2 and ((s1 is None and s2 is None) or np.array_equal(s1, s2))
+        with pytest.raises(RuntimeError, match="asks for a prediction with"):
+            net.serve_frames(offs[:1], np.array([7], np.int32), np.array([tp.REQ_RESET], np.uint32))
+    finally:
+        for m in (net, other):
+            m.unregister_transport()
+        for seg in (t, t2):
+            seg.shutdown()
+            seg.close()
+        other.close()
