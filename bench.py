@@ -341,7 +341,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 fe_traffic = json.load(f).get("frame_frontend_210x160x3_n%d" % nf)
         fe = {"frames_per_sec": nf / (us * 1e-6), "frames_per_launch": nf, "launch_us": us,
-              "roofline": {"kernel": "frame_frontend_kernel<true>", "bound": "hbm", "achieved": nf * fbytes / (us * 1e-6) / 1e9,
+              "roofline": {"kernel": "frame_frontend_kernel<3>", "bound": "hbm", "achieved": nf * fbytes / (us * 1e-6) / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nf * fbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                            "algorithmic_bytes_per_frame": fbytes, "traffic": fe_traffic},
               "note": "frames resident in HBM; gray (f64) + per-frame min/max bytescale + Pillow-exact bilinear 84x84 + push "
