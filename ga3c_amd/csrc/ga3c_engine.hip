@@ -133,10 +133,15 @@ struct ga3c_net {
   int64_t n = 0;   // arena floats
   float* theta[2] = {nullptr, nullptr};
   float* theta_pk[2] = {nullptr, nullptr};   // dense1/w of theta[i] in dense1_fwd's fragment order
-  int cur = 0;
+  // Double-buffered weights.  `latest` is the buffer the newest optimizer step wrote (train-stream order; everything on
+  // the train side reads it); `cur` is the buffer prediction lanes read: it follows `latest` only once that step has
+  // FINISHED on the GPU, so a prediction never queues behind a train step in flight (it reads weights one step old
+  // instead -- the reference's predictors read weights in the middle of an update).
+  std::atomic<int> cur{0};
+  int latest = 0;
+  bool must_wait[2] = {false, false};   // cur was advanced before theta_ready[cur] completed (steps enqueued back to back)
   float *grad = nullptr, *ms = nullptr, *mom = nullptr;
-  hipEvent_t theta_ready[2] = {nullptr, nullptr};
-  bool ready_recorded[2] = {false, false};
+  hipEvent_t theta_ready[2] = {nullptr, nullptr};   // recorded on the train stream behind the step that wrote theta[i]
   std::mutex ready_mu;
   std::shared_mutex wmu;   // shared: a forward pass picking/reading theta[cur]; unique: the optimizer flip
   std::vector<Lane*> lanes;
@@ -350,16 +355,20 @@ int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, fl
 
 int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* out_v) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
-  const int idx = net->cur;
+  int idx = net->cur.load();
+  if (net->latest != idx && hipEventQuery(net->theta_ready[net->latest]) == hipSuccess) {
+    // the optimizer step that wrote the other buffer has finished: predictions move over to it
+    std::lock_guard<std::mutex> g(net->ready_mu);
+    net->must_wait[net->latest] = false;
+    net->cur.store(net->latest);
+    idx = net->latest;
+  }
+  bool wait;
   {
     std::lock_guard<std::mutex> g(net->ready_mu);
-    if (!net->ready_recorded[idx]) {
-      // first reader since the optimizer wrote theta[idx]: mark the tail of the train stream
-      HIPCHK(hipEventRecord(net->theta_ready[idx], net->tr.st));
-      net->ready_recorded[idx] = true;
-    }
+    wait = net->must_wait[idx];
   }
-  HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
+  if (wait) HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
   CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
@@ -371,7 +380,7 @@ int train_grads(ga3c_net* net, TrainLane& t, int B, float beta) {
   int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    idx = net->cur;   // synchronous mode: only lane 0's stream ever flips it, and that is ordered behind us
+    idx = net->latest;   // the newest weights: written by this same stream (synchronous mode) or in place (Hogwild)
   }
   CHK(launch_forward(net, t.f, idx, B, t.st, true, &t, beta));
   CHK(launch_backward(net, t, net->theta[idx], B));
@@ -383,7 +392,7 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
     // The reference's NT trainer threads run sess.run(train_op) concurrently on shared variables without locking
     // (Server.py:132-134, TF use_locking=False): every lane updates theta / ms in place from its own stream; reads by
     // other lanes may see a step half applied, and two optimizer kernels may race on an element.
-    const int idx = net->cur;
+    const int idx = net->latest;
     CHK(launch_rmsprop(net, t.grad, t.scales, net->theta[idx], net->theta[idx], net->theta_pk[idx], lr, t.st));
     net->step.fetch_add(1);
     return GA3C_OK;
@@ -391,7 +400,13 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
   if (net->comm && net->world > 1)
     NCCLCHK(ncclAllReduce(t.grad, t.grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
   std::unique_lock<std::shared_mutex> lk(net->wmu);
-  const int idx = net->cur, other = 1 - idx;
+  const int idx = net->latest, other = 1 - idx;
+  if (net->cur.load() != idx) {
+    // no prediction has moved over to the previous step's weights yet, and this step is about to overwrite the buffer
+    // predictions still read: move them now; they wait for that step only if it is still in flight
+    net->must_wait[idx] = hipEventQuery(net->theta_ready[idx]) != hipSuccess;
+    net->cur.store(idx);
+  }
   // Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only
   // when a prediction lane has really touched the buffer about to be overwritten.
   for (Lane* L : net->lanes) {
@@ -401,8 +416,8 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
     }
   }
   CHK(launch_rmsprop(net, t.grad, t.scales, net->theta[idx], net->theta[other], net->theta_pk[other], lr, t.st));
-  net->ready_recorded[other] = false;   // a lane that needs this buffer records theta_ready itself (lane_forward)
-  net->cur = other;
+  HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
+  net->latest = other;
   net->step.fetch_add(1);
   return GA3C_OK;
 }
@@ -650,6 +665,11 @@ int sync_all(ga3c_net* net) {
   for (Lane* L : net->lanes) HIPCHK(hipStreamSynchronize(L->st));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   for (TrainLane* t : net->xtr) HIPCHK(hipStreamSynchronize(t->st));
+  {
+    std::lock_guard<std::mutex> g(net->ready_mu);   // nothing is in flight: the newest weights are complete
+    net->must_wait[0] = net->must_wait[1] = false;
+    net->cur.store(net->latest);
+  }
   return GA3C_OK;
 }
 
@@ -807,7 +827,7 @@ int ga3c_net_param_count(ga3c_net* net, int64_t* count) {
 
 static float* arena_ptr(ga3c_net* net, int which) {
   switch (which) {
-    case 0: return net->theta[net->cur];
+    case 0: return net->theta[net->latest];
     case 1: return net->ms;
     case 2: return net->mom;
     case 3: return net->grad;
@@ -843,8 +863,8 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
   if (!dst) return fail(GA3C_EINVAL, "arena selector %d not in [0,3]", which);
   HIPCHK(hipMemcpy(dst, in, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
   if (which == 0) {
-    hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, net->tr.st, net->theta[net->cur] + OFF_WD,
-                       net->theta_pk[net->cur]);
+    hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, net->tr.st, net->theta[net->latest] + OFF_WD,
+                       net->theta_pk[net->latest]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(net->tr.st));
   }
@@ -1281,7 +1301,7 @@ static int resident_predict_locked(ga3c_net* net, int B) {
   int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    idx = net->cur;
+    idx = net->latest;
   }
   return launch_forward(net, net->tr.f, idx, B, net->tr.st, false, nullptr, 0.f);
 }
@@ -1347,7 +1367,7 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    idx = net->cur;
+    idx = net->latest;   // == cur after the sync_all above
   }
   const auto h0 = std::chrono::steady_clock::now();
   for (int i = 0; i < iters; ++i) {
@@ -1399,7 +1419,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
   TrainLane& t = net->tr;
-  const float* th = net->theta[net->cur];
+  const float* th = net->theta[net->latest];
   float* g = net->grad;
   const int B = batch;
   const std::string k(kernel);
@@ -1420,10 +1440,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
       if (B <= 256)
-        TL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), t.f.n2, net->theta_pk[net->cur], t.f.part, B, ks,
+        TL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), t.f.n2, net->theta_pk[net->latest], t.f.part, B, ks,
            KSTEPS_DENSE / ks);
       else
-        TL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), t.f.n2, net->theta_pk[net->cur], t.f.part, B, ks,
+        TL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), t.f.n2, net->theta_pk[net->latest], t.f.part, B, ks,
            KSTEPS_DENSE / ks);
     } else if (k == "conv1_dw") {
       TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
@@ -1470,9 +1490,9 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2);
     } else if (k == "rmsprop") {
       const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
-      TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->cur], net->ms, net->mom, t.grad, net->n,
+      TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->latest], net->ms, net->mom, t.grad, net->n,
          0.0f, 1.0f - net->cfg.rmsprop_decay, 0.0f, net->cfg.rmsprop_epsilon, net->tt, t.scales,
-         net->theta_pk[net->cur]);
+         net->theta_pk[net->latest]);
     } else {
       return fail(GA3C_EINVAL, "unknown kernel '%s'", kernel);
     }
