@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--hogwild", action="store_true")
     ap.add_argument("--python-predictor", action="store_true", help="keep ThreadPredictor's loop in Python")
+    ap.add_argument("--dynamic", action="store_true", help="ThreadDynamicAdjustment random walk every 2 s (soak test)")
     ap.add_argument("--frames", choices=["planes", "rgb-host", "rgb-device"], default="planes",
                     help="frame source / where the reference's front-end runs (Config.FRAME_SOURCE, Config.FRONTEND)")
     args = ap.parse_args()
@@ -40,7 +41,8 @@ def main():
     from Server import Server
 
     Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = args.agents, args.predictors, args.trainers
-    Config.DYNAMIC_SETTINGS = False
+    Config.DYNAMIC_SETTINGS = bool(args.dynamic)
+    Config.DYNAMIC_SETTINGS_STEP_WAIT, Config.DYNAMIC_SETTINGS_INITIAL_WAIT = 2, 2
     Config.PREDICTION_BATCH_SIZE = args.batch
     Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
     Config.TRAIN_MODELS = not args.no_train
@@ -72,7 +74,8 @@ def main():
         return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step,
                 "batches": sum(p.batches for p in srv.predictors),
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")}, "srv_cpu": cpu_of([me]), "agent_cpu": cpu_of(kids),
-                "n_kids": len(kids)}
+                "n_kids": len(kids), "n_agents": len(srv.agents), "n_pred": len(srv.predictors), "n_train": len(srv.trainers),
+                "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive())}
 
     def sampler():
         time.sleep(args.warm)
@@ -99,7 +102,9 @@ def main():
         "server_cpu_cores": round((b["srv_cpu"] - a["srv_cpu"]) / dt, 2),
         "agent_cpu_cores": round((b["agent_cpu"] - a["agent_cpu"]) / dt, 2),
         "agent_cpu_us_per_step": round((b["agent_cpu"] - a["agent_cpu"]) / max(1, pred) * 1e6, 1),
-        "agent_wall_us_per_step": round(dt * args.agents / max(1, pred) * 1e6, 1)}))
+        "agent_wall_us_per_step": round(dt * args.agents / max(1, pred) * 1e6, 1),
+        "workers_at_end": {"agents": b["n_agents"], "predictors": b["n_pred"], "trainers": b["n_train"]},
+        "threads_died": b["died"]}))
 
 
 if __name__ == "__main__":
