@@ -28,6 +28,7 @@ class Server:
         # one Server per GPU under torch.distributed.run: lock-step training over RCCL (DataParallel.py)
         self.dp = engine_group
         self.dp_lock = threading.Lock()
+        self.batch_lock = threading.Lock()      # one trainer at a time fills a batch (ThreadTrainer.py)
         self.dp_started = False
         self.stop_step = None
         self.stats = ProcessStats()

@@ -4,6 +4,13 @@ queue until the batch holds MORE than TRAINING_MIN_BATCH_SIZE rows, then one ser
 Rollouts arrive as slots of the shared-memory transport (states, f32 returns, int32 actions);
 rows are copied once into a staging batch instead of the reference's repeated np.concatenate.
 x2_ and done_ are not transported (unused by the A3C nets, NetworkVP.py:254); train_model gets None.
+
+Zero-copy intake keeps a rollout's slot until the GPU has read its rows, which the reference's queue never does
+(training_q.get() frees the entry).  Two rules keep that from starving the agents of slots: only one trainer at a time
+fills a batch (Server.batch_lock; the others are training or waiting their turn), and a trainer that holds slots while
+the agents have none left and nothing is queued SPILLS: it copies the rows it holds into a host batch, gives the slots
+back and finishes that batch through the host-buffer path.  (Seen as a dead stop with TRAINING_MIN_BATCH_SIZE = 511,
+MAX_QUEUE_SIZE = 100 and two trainers.)
 """
 from threading import Thread
 
@@ -20,6 +27,7 @@ class ThreadTrainer(Thread):
         self.server = server
         self.transport = transport if transport is not None else server.transport
         self.exit_flag = False
+        self.spills = 0                 # batches finished through the host path because the agents ran out of slots
 
     def run(self):
         t = self.transport
@@ -39,42 +47,62 @@ class ThreadTrainer(Thread):
         r_stage = np.zeros(cap, np.float32)
         a_stage = np.zeros(cap, np.int32)
         eye = np.eye(t.num_actions, dtype=np.float32)
+        holding = zero_copy and not on_device
+        turn = getattr(self.server, "batch_lock", None) if holding else None
         while not self.exit_flag:
             batch_size = 0
-            held = []                                   # zero-copy: slots stay ours until the GPU has read them
-            while batch_size <= Config.TRAINING_MIN_BATCH_SIZE and not self.exit_flag:
-                slot = t.pop_rollout(Config.QUEUE_TIMEOUT_MS)
-                if slot == -3:
-                    continue                            # timeout: look at exit_flag again
-                if slot < 0:
-                    return                              # transport shut down
-                rows = t.rows(slot)
-                states, returns, actions = t.rollout_views(slot)
-                r_stage[batch_size:batch_size + rows] = returns[:rows]
-                a_stage[batch_size:batch_size + rows] = actions[:rows]
-                if on_device:
-                    seq_stage[batch_size:batch_size + rows] = states[:rows, :8].view(np.int64).ravel()
-                    agent_stage[batch_size:batch_size + rows] = states[:rows, 8:12].view(np.int32).ravel()
-                    t.release(slot)
-                elif zero_copy:
-                    off_stage[batch_size:batch_size + rows] = t.rollout_row_offsets(slot, rows)
-                    held.append(slot)
-                else:
-                    x_stage[batch_size:batch_size + rows] = states[:rows]
-                    t.release(slot)
-                batch_size += rows
+            held = []                                   # zero-copy: (slot, first row, rows) stay ours until the GPU has read them
+            spilled = False
+            if turn:
+                while not turn.acquire(timeout=Config.QUEUE_TIMEOUT_MS / 1000.0):
+                    if self.exit_flag:
+                        return
+            try:
+                while batch_size <= Config.TRAINING_MIN_BATCH_SIZE and not self.exit_flag:
+                    if held and t.free_count() == 0 and t.ready_count() == 0:
+                        # every slot is ours or another trainer's and the agents are waiting for one: spill
+                        if x_stage is None:
+                            x_stage = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)
+                        for slot, first, rows in held:
+                            x_stage[first:first + rows] = t.rollout_views(slot)[0][:rows]
+                            t.release(slot)
+                        held, spilled = [], True
+                        self.spills += 1
+                    slot = t.pop_rollout(5 if held else Config.QUEUE_TIMEOUT_MS)
+                    if slot == -3:
+                        continue                        # timeout: look at exit_flag (and at the slot supply) again
+                    if slot < 0:
+                        return                          # transport shut down
+                    rows = t.rows(slot)
+                    states, returns, actions = t.rollout_views(slot)
+                    r_stage[batch_size:batch_size + rows] = returns[:rows]
+                    a_stage[batch_size:batch_size + rows] = actions[:rows]
+                    if on_device:
+                        seq_stage[batch_size:batch_size + rows] = states[:rows, :8].view(np.int64).ravel()
+                        agent_stage[batch_size:batch_size + rows] = states[:rows, 8:12].view(np.int32).ravel()
+                        t.release(slot)
+                    elif holding and not spilled:
+                        off_stage[batch_size:batch_size + rows] = t.rollout_row_offsets(slot, rows)
+                        held.append((slot, batch_size, rows))
+                    else:
+                        x_stage[batch_size:batch_size + rows] = states[:rows]
+                        t.release(slot)
+                    batch_size += rows
+            finally:
+                if turn:
+                    turn.release()
             if batch_size and Config.TRAIN_MODELS and not self.exit_flag:
                 if on_device:
                     self.server.train_model_frames(agent_stage[:batch_size], seq_stage[:batch_size], r_stage[:batch_size],
                                                    eye[a_stage[:batch_size]], self.id)
-                elif zero_copy:
+                elif holding and not spilled:
                     self.server.train_model_rows(off_stage[:batch_size], r_stage[:batch_size],
                                                  eye[a_stage[:batch_size]], self.id)
                 else:
                     xb = x_stage[:batch_size] if u8 else x_stage[:batch_size].view(np.float32)
                     self.server.train_model(xb.reshape((batch_size,) + state_dim), r_stage[:batch_size],
                                             eye[a_stage[:batch_size]], None, None, self.id)
-            for slot in held:
+            for slot, _, _ in held:
                 t.release(slot)
             if self.exit_flag or batch_size == 0:
                 break

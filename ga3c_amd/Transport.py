@@ -138,6 +138,9 @@ class Transport:
     def ready_count(self):
         return self._lib.ga3c_tq_ready_count(self._h)
 
+    def free_count(self):
+        return self._lib.ga3c_tq_free_count(self._h)
+
 
 def unique_name(tag="ga3c"):
     return "/%s_%d_%d" % (tag, os.getpid(), int.from_bytes(os.urandom(3), "little"))

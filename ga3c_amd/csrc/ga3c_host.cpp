@@ -682,4 +682,9 @@ int ga3c_tq_ready_count(ga3c_shm* shm) {
   return (int)ring_size(&shm->hdr()->readyq);
 }
 
+int ga3c_tq_free_count(ga3c_shm* shm) {
+  if (!shm) return fail(GA3C_H_EINVAL, "null argument");
+  return (int)ring_size(&shm->hdr()->freeq);
+}
+
 }  // extern "C"

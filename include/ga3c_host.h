@@ -133,6 +133,7 @@ int ga3c_tq_pop(ga3c_shm* shm, int32_t timeout_ms);                     /* -> re
 int ga3c_tq_rows(ga3c_shm* shm, int32_t slot);
 int ga3c_tq_release(ga3c_shm* shm, int32_t slot);
 int ga3c_tq_ready_count(ga3c_shm* shm);
+int ga3c_tq_free_count(ga3c_shm* shm);    /* slots no producer and no consumer holds; 0 = producers are blocked */
 
 #ifdef __cplusplus
 }

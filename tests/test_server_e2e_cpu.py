@@ -193,3 +193,47 @@ def test_rgb_source_with_host_front_end_feeds_reference_planes(monkeypatch):
     assert dev.on_device and np.array_equal(dev.frame, raw.frame) and dev.frames_queued == 1
     dev.step(0)
     assert dev.current_u8 is None and dev.frames_queued == 2
+
+
+class _ZeroCopyStandIn(_StandInModel):
+    """A stand-in with the zero-copy entry points, so that trainers keep rollout slots while they fill a batch."""
+
+    def register_transport(self, transport):
+        self.transport = transport
+        self.offset_batches = []
+
+    def unregister_transport(self):
+        self.transport = None
+
+    def predict_offsets(self, offsets):
+        b = len(offsets)
+        return np.full((b, self.n_act), 1.0 / self.n_act, np.float32), np.zeros(b, np.float32)
+
+    def train_offsets(self, offsets, y_r, a):
+        self.offset_batches.append(len(offsets))
+
+
+@pytest.mark.timeout(120)
+def test_trainers_cannot_starve_the_agents_of_rollout_slots(tmp_path, monkeypatch):
+    """TRAINING_MIN_BATCH_SIZE larger than what the rollout slots hold, two trainers, zero-copy intake: without the
+    trainers' turn-taking and spill rule every slot ends up held by a trainer waiting for more rows and the engine
+    stops dead (found on the GPU box with batch 512, MAX_QUEUE_SIZE 100).  Batches must keep coming, whole."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=4, PREDICTORS=1, TRAINERS=2, SYNTHETIC_EPISODE_LENGTH=50, TIME_MAX=5, DYNAMIC_SETTINGS=False,
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=59, NUM_ACTIONS=6, MAX_QUEUE_SIZE=6, ZERO_COPY=True).items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    model = _ZeroCopyStandIn(6)
+    srv = Server(model=model, max_agents=8)
+    assert srv.zero_copy and srv.transport.train_slots == 6            # 6 slots x 6 rows < 60 rows per batch
+    trainers = []
+    real_add = srv.add_trainer
+    monkeypatch.setattr(srv, "add_trainer", lambda: (real_add(), trainers.append(srv.trainers[-1])))
+    srv.main(max_seconds=6)
+    batches = model.train_rows + model.offset_batches
+    assert len(batches) >= 5 and min(batches) >= 60 and srv.training_step == len(batches)
+    assert model.train_rows and model.train_dtypes == {"uint8"}         # spilled batches went through the host path
+    spills = sum(t.spills for t in trainers)                           # a batch spilled at shutdown may never be trained
+    assert len(model.train_rows) <= spills <= len(model.train_rows) + 2
