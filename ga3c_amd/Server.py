@@ -43,8 +43,14 @@ class Server:
         if self.device_frontend:
             state_bytes = (Config.FRAME_HEIGHT * Config.FRAME_WIDTH * 3 + 15) // 16 * 16
             row_bytes = 16
+        # training_q.get() frees a queue entry at once (ThreadTrainer.py:49); zero-copy trainers keep a rollout's slot
+        # until the GPU has read it, so the slots they hold come on top of the queue bound
+        slots = int(Config.ROLLOUT_SLOTS)
+        if slots <= 0:
+            per_batch = -(-(Config.TRAINING_MIN_BATCH_SIZE + 1) // max(Config.TIME_MAX, 1))
+            slots = Config.MAX_QUEUE_SIZE + (0 if self.device_frontend else 2 * max(Config.TRAINERS, 2) * per_batch)
         self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
-                                             Config.MAX_QUEUE_SIZE, Config.TIME_MAX + 1, row_bytes)
+                                             slots, Config.TIME_MAX + 1, row_bytes)
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
                                                              self.state_dim)
         if self.dp is not None and hasattr(self.model, "comm_init"):
@@ -57,7 +63,7 @@ class Server:
             if not (self.zero_copy and hasattr(self.model, "frames_config")):
                 raise RuntimeError("FRONTEND = 'device' needs ZERO_COPY and a model with the frames_* entry points")
             # an agent can be ahead of the trainers by every rollout in flight plus the one it is filling
-            history = Config.FRAME_HISTORY or (Config.MAX_QUEUE_SIZE + 2) * (Config.TIME_MAX + 1) + 8
+            history = Config.FRAME_HISTORY or (self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8
             self.model.frames_config(self.max_agents, Config.FRAME_HEIGHT, Config.FRAME_WIDTH, 3, history)
         if Config.LOAD_CHECKPOINT:
             try:

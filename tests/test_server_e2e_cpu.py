@@ -222,7 +222,7 @@ def test_trainers_cannot_starve_the_agents_of_rollout_slots(tmp_path, monkeypatc
     from Config import Config
     monkeypatch.chdir(tmp_path)
     for k, v in dict(AGENTS=4, PREDICTORS=1, TRAINERS=2, SYNTHETIC_EPISODE_LENGTH=50, TIME_MAX=5, DYNAMIC_SETTINGS=False,
-                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=59, NUM_ACTIONS=6, MAX_QUEUE_SIZE=6, ZERO_COPY=True).items():
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=59, NUM_ACTIONS=6, ROLLOUT_SLOTS=6, ZERO_COPY=True).items():
         monkeypatch.setattr(Config, k, v)
     from Server import Server
     model = _ZeroCopyStandIn(6)
