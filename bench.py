@@ -374,6 +374,10 @@ def main():
                           note="synthetic Python agents (PCG64 frames) on this box's host cores; predictions served and "
                                "train steps taken by the engine over the steady window of the run (whole_run includes "
                                "forking the agents)")
+        # BASELINE configs[2] names 64 agents for the predictor + trainer engine
+        r64 = run_engine(None, max(4.0, args.e2e_seconds * 0.75), 2 * args.e2e_agents, B, A)
+        out["e2e"]["agents_x2"] = {k: r64[k] for k in ("predictions_per_sec", "training_steps_per_sec", "mean_predict_batch",
+                                                        "seconds", "agents", "predictors", "trainers")}
         # the same engine fed with raw 210x160x3 emulator frames: the reference's front-end in the agents (host) against the
         # HIP front-end with device-resident frame queues and (agent, plane) rollouts
         half = max(4.0, args.e2e_seconds * 0.75)
