@@ -67,6 +67,9 @@ struct Fwd {   // forward workspace of one lane (device pointers)
         *v = nullptr;
   uint8_t* xu8 = nullptr;
   bool x_u8 = false;   // the staged batch lives in xu8 (uint8 frames) and the conv kernels convert while reading
+  // prediction intake fused into the conv stack: sample b lies src_off[b] bytes behind src_base (nullptr: dense batch)
+  const uint8_t* src_base = nullptr;
+  const int64_t* src_off = nullptr;
 };
 
 struct Lane {
@@ -211,12 +214,13 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
   const float* th = net->theta[idx];
-  const void* xin = f.x_u8 ? (const void*)f.xu8 : (const void*)f.x;
+  const void* xin = f.src_off ? (const void*)f.src_base : (f.x_u8 ? (const void*)f.xu8 : (const void*)f.x);
+  if (f.src_off && !(net->fused_conv && B <= 160)) return fail(GA3C_ESTATE, "scattered intake needs the fused conv stack");
   if (net->fused_conv && B <= 160) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
     const size_t lds = CS_LDS_FLOATS * sizeof(float);
 #define CSTACK(T, U)                                                                                                \
   hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, th + OFF_W1, th + OFF_B1, \
-                     th + OFF_W2, th + OFF_B2, f.n1, f.n2, B)
+                     th + OFF_W2, th + OFF_B2, f.n1, f.n2, B, f.src_off)
     if (train) { if (f.x_u8) CSTACK(true, true); else CSTACK(true, false); }
     else { if (f.x_u8) CSTACK(false, true); else CSTACK(false, false); }
 #undef CSTACK
@@ -308,17 +312,28 @@ int launch_rmsprop(ga3c_net* net, const float* grad, float* scales, const float*
 // forward on a prediction lane: pick the current weights under the shared lock
 // the kernels of one prediction step on lane L: the intake gather (offsets already in L.h_off), then the forward pass
 int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v) {
+  L.f.src_base = nullptr;
+  L.f.src_off = nullptr;
   if (mode != STEP_RESIDENT) {
     const bool u8 = mode != STEP_GATHER_F32;
     const uint8_t* base = mode == STEP_QUEUES ? reinterpret_cast<const uint8_t*>(net->fr.stacks) : net->reg_dev;
-    const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.xu8, B);
-    else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.x, B);
     L.f.x_u8 = u8;
+    if (net->fused_conv && B <= 160) {
+      // small batches (every engine batch): the conv stack reads the scattered states itself -- one launch less
+      L.f.src_base = base;
+      L.f.src_off = L.h_off;
+    } else {
+      const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.xu8, B);
+      else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.x, B);
+    }
   }
-  return launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
+  const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
+  L.f.src_base = nullptr;
+  L.f.src_off = nullptr;
+  return rc;
 }
 
 void drop_graphs(Lane& L) {
@@ -1433,10 +1448,12 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "conv_stack_fwd") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
-                            t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B);
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
+                            (const int64_t*)nullptr);
     } else if (k == "conv_stack_fwd_u8") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
-                            t.ev0, t.ev1, 0, (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B);
+                            t.ev0, t.ev1, 0, (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
+                            (const int64_t*)nullptr);
     } else if (k == "dense1_fwd") {
       const int ks = dense_ks(B);
       if (B <= 256)

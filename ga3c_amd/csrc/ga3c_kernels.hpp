@@ -293,7 +293,8 @@ template <bool TRAIN, bool U8>
 __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w1,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, float* __restrict__ n1,
-                                                             float* __restrict__ n2, int B) {
+                                                             float* __restrict__ n2, int B,
+                                                             const int64_t* __restrict__ src_off) {
   extern __shared__ __attribute__((aligned(16))) float cs_lds[];
   float* img = cs_lds;
   float* n1l = cs_lds + CS_X_FLOATS;
@@ -302,6 +303,10 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x >> 1, h = blockIdx.x & 1;
   if (b >= B) return;                                        // block-uniform guard: the grid is B * 2
+  // src_off: the states are not a dense batch but lie src_off[b] bytes behind x (transport slots in registered host
+  // memory, or the device-side frame queues): the intake gather happens here, in the staging loads
+  const void* xs = src_off ? static_cast<const void*>(static_cast<const char*>(x) + src_off[b]) : x;
+  const size_t sb = src_off ? 0 : (size_t)b;
   // conv2 rows 0..4 | 5..10: then each half has <= 16 conv1 tiles and <= 16 conv2 items, one per wave
   const int c2r0 = h ? 5 : 0, c2nr = h ? 6 : 5;              // conv2 output rows of this half
   const int n1r0 = h ? 9 : 0, n1nr = h ? 12 : 11;            // n1 rows it needs (rows 9,10 are computed by both)
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
     const int row = idx / C1_PW, col = idx - row * C1_PW;
     const int yy = xr0 + row, xx = col - 2;
     const bool ok = idx < npx && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-    sx[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
+    sx[i] = ok ? load_px<U8>(xs, sb, yy * IMG + xx) : zero4();
   }
   sw1 = ld4(w1 + 4 * threadIdx.x);                           // W1[256][16] = 1024 float4
   sw2[0] = ld4(w2 + 4 * threadIdx.x);                        // W2[256][32] = 2048 float4
