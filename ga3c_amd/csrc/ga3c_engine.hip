@@ -143,6 +143,9 @@ struct ga3c_net {
   std::atomic<int> cur{0};
   int latest = 0;
   bool must_wait[2] = {false, false};   // cur was advanced before theta_ready[cur] completed (steps enqueued back to back)
+  bool event_valid[2] = {false, false}; // theta_ready[i] was recorded behind the step that wrote theta[i]
+  std::atomic<uint64_t> pred_seq{0};    // prediction steps launched so far; the optimizer records theta_ready only while
+  uint64_t pred_seen = 0;               // predictions are arriving (an event per step costs a train-only loop ~3 us)
   float *grad = nullptr, *ms = nullptr, *mom = nullptr;
   hipEvent_t theta_ready[2] = {nullptr, nullptr};   // recorded on the train stream behind the step that wrote theta[i]
   std::mutex ready_mu;
@@ -370,18 +373,34 @@ int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, fl
 
 int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* out_v) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
+  net->pred_seq.fetch_add(1);
   int idx = net->cur.load();
-  if (net->latest != idx && hipEventQuery(net->theta_ready[net->latest]) == hipSuccess) {
-    // the optimizer step that wrote the other buffer has finished: predictions move over to it
+  if (net->latest != idx) {
     std::lock_guard<std::mutex> g(net->ready_mu);
-    net->must_wait[net->latest] = false;
-    net->cur.store(net->latest);
-    idx = net->latest;
+    const int nw = net->latest;
+    if (!net->event_valid[nw]) {
+      // the optimizer saw no predictions around and skipped the event: mark the tail of the train stream now
+      HIPCHK(hipEventRecord(net->theta_ready[nw], net->tr.st));
+      net->event_valid[nw] = true;
+    }
+    if (net->cur.load() != nw && hipEventQuery(net->theta_ready[nw]) == hipSuccess) {
+      // the optimizer step that wrote the other buffer has finished: predictions move over to it
+      net->must_wait[nw] = false;
+      net->cur.store(nw);
+    }
+    idx = net->cur.load();
   }
   bool wait;
   {
     std::lock_guard<std::mutex> g(net->ready_mu);
     wait = net->must_wait[idx];
+    if (wait) {
+      if (!net->event_valid[idx]) {   // nobody has marked the step that wrote this buffer yet
+        HIPCHK(hipEventRecord(net->theta_ready[idx], net->tr.st));
+        net->event_valid[idx] = true;
+      }
+      if (hipEventQuery(net->theta_ready[idx]) == hipSuccess) wait = net->must_wait[idx] = false;
+    }
   }
   if (wait) HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
   CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
@@ -419,7 +438,8 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
   if (net->cur.load() != idx) {
     // no prediction has moved over to the previous step's weights yet, and this step is about to overwrite the buffer
     // predictions still read: move them now; they wait for that step only if it is still in flight
-    net->must_wait[idx] = hipEventQuery(net->theta_ready[idx]) != hipSuccess;
+    // (without an event -- no predictions were around -- the next prediction marks the train stream itself and waits)
+    net->must_wait[idx] = net->event_valid[idx] ? hipEventQuery(net->theta_ready[idx]) != hipSuccess : true;
     net->cur.store(idx);
   }
   // Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only
@@ -431,7 +451,10 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
     }
   }
   CHK(launch_rmsprop(net, t.grad, t.scales, net->theta[idx], net->theta[other], net->theta_pk[other], lr, t.st));
-  HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
+  const uint64_t seq = net->pred_seq.load();
+  net->event_valid[other] = seq != net->pred_seen;   // predictions are arriving: give them an event to poll
+  net->pred_seen = seq;
+  if (net->event_valid[other]) HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
   net->latest = other;
   net->step.fetch_add(1);
   return GA3C_OK;
@@ -463,10 +486,18 @@ int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, cons
   return GA3C_OK;
 }
 
-int read_losses(ga3c_net*, TrainLane& t, float* losses) {
+int read_losses(ga3c_net* net, TrainLane& t, float* losses) {
   float* hl = t.h_out;
   HIPCHK(hipMemcpyAsync(hl, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
   HIPCHK(hipStreamSynchronize(t.st));
+  if (!net->hogwild) {
+    // the step this call enqueued has finished: predictions read its weights from now on (a caller that trains and
+    // then predicts sees the new weights; in the engine the trainer thread moves the predictors over right here)
+    std::shared_lock<std::shared_mutex> lk(net->wmu);
+    std::lock_guard<std::mutex> g(net->ready_mu);
+    net->must_wait[net->latest] = false;
+    net->cur.store(net->latest);
+  }
   if (losses) memcpy(losses, hl, 3 * sizeof(float));
   return GA3C_OK;
 }
@@ -683,7 +714,7 @@ int sync_all(ga3c_net* net) {
   {
     std::lock_guard<std::mutex> g(net->ready_mu);   // nothing is in flight: the newest weights are complete
     net->must_wait[0] = net->must_wait[1] = false;
-    net->cur.store(net->latest);
+    net->cur.store(net->latest);   // (event_valid is irrelevant while cur == latest)
   }
   return GA3C_OK;
 }
