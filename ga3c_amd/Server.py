@@ -203,6 +203,8 @@ class Server:
 
     def shutdown(self):
         self.dynamic_adjustment.exit_flag = True
+        if self.dynamic_adjustment.is_alive():      # it may still be starting workers (a run that ends at once)
+            self.dynamic_adjustment.join(timeout=30)
         for a in self.agents:
             a.exit_flag.value = True
         self.transport.shutdown()

@@ -6,8 +6,7 @@ One deliberate difference: the reference's branch that
 repeats the `<` condition of the add branch (:75,:79) and can never run; the evident intent (`>`)
 is implemented here.  Human-reference agents (:84-93) are pyperrace-only and out of scope.
 """
-import time
-from threading import Thread
+from threading import Event, Thread
 
 import numpy as np
 
@@ -24,7 +23,18 @@ class ThreadDynamicAdjustment(Thread):
         self.predictor_count = Config.PREDICTORS
         self.agent_count = Config.AGENTS
         self.temporal_training_count = 0
-        self.exit_flag = False
+        self._halt = Event()            # set through exit_flag; the waits below end at once
+
+    @property
+    def exit_flag(self):
+        return self._halt.is_set()
+
+    @exit_flag.setter
+    def exit_flag(self, value):
+        if value:
+            self._halt.set()
+        else:
+            self._halt.clear()
 
     @staticmethod
     def _resize(current, wanted, add, remove):
@@ -57,7 +67,7 @@ class ThreadDynamicAdjustment(Thread):
         self.update_stats()
         if not self.enabled:
             return
-        time.sleep(Config.DYNAMIC_SETTINGS_INITIAL_WAIT)
+        self._halt.wait(Config.DYNAMIC_SETTINGS_INITIAL_WAIT)
         while not self.exit_flag:
             before = (self.trainer_count, self.predictor_count, self.agent_count)
             self.random_walk()
@@ -66,7 +76,8 @@ class ThreadDynamicAdjustment(Thread):
             old_count = self.temporal_training_count
             self.enable_disable_components()
             self.temporal_training_count = 0
-            time.sleep(Config.DYNAMIC_SETTINGS_STEP_WAIT)
+            if self._halt.wait(Config.DYNAMIC_SETTINGS_STEP_WAIT):
+                break
             if self.temporal_training_count < old_count:          # it got worse: go back
                 self.trainer_count, self.predictor_count, self.agent_count = before
             self.update_stats()

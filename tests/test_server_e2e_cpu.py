@@ -237,3 +237,19 @@ def test_trainers_cannot_starve_the_agents_of_rollout_slots(tmp_path, monkeypatc
     assert model.train_rows and model.train_dtypes == {"uint8"}         # spilled batches went through the host path
     spills = sum(t.spills for t in trainers)                           # a batch spilled at shutdown may never be trained
     assert len(model.train_rows) <= spills <= len(model.train_rows) + 2
+
+
+@pytest.mark.timeout(60)
+def test_a_run_that_ends_at_once_shuts_down_cleanly(tmp_path, monkeypatch):
+    """EPISODES already reached (e.g. _play.sh on a checkpoint from a later episode): the main loop ends while the
+    adjustment thread is still starting workers; shutdown must wait for it instead of joining unstarted threads."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=3, PREDICTORS=2, TRAINERS=2, DYNAMIC_SETTINGS=False, SAVE_MODELS=False, EPISODES=0,
+                     NUM_ACTIONS=6).items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    srv = Server(model=_StandInModel(6), max_agents=8)
+    srv.main()
+    assert not srv.agents and not srv.predictors and not srv.trainers
