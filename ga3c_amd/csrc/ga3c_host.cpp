@@ -23,6 +23,9 @@
 #include <vector>
 
 #include "ga3c_resample.hpp"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace {
 
@@ -268,62 +271,255 @@ int ga3c_returns_nstep(const double* rewards, int32_t T, double gamma, double bo
   return GA3C_H_OK;
 }
 
+// ---- host frame front-end.  Same arithmetic as oracle/frame_frontend.py and frame_frontend_kernel, arranged for speed:
+// resample tables cached per geometry, scratch buffers kept per thread, and the three hot loops compiled twice -- for
+// x86-64-v3 (AVX2 + FMA: the compiler vectorises them, std::fma is one instruction) and for the baseline ISA -- with the
+// choice made once at run time.  Results do not depend on the path: every product and sum is rounded where numpy
+// rounds it (-ffp-contract=off, explicit fma only in the gray product).
+namespace {
+
+struct FrameScratch {
+  std::vector<double> gray;
+  std::vector<uint8_t> img, tmp;
+  ga3c::ResampleTable th, tv;
+  // horizontal pass, 4 outputs per step: first source byte of the group, and per tap a byte-shuffle mask that drops each
+  // output's tap byte into its 32-bit lane plus the four weights; empty when a group's sources span more than 16 bytes
+  std::vector<int32_t> hbase, hweight;   // [groups], [groups][ksize][4]
+  std::vector<uint8_t> hsel;             // [groups][ksize][16]
+};
+
+void build_hpass_plan(FrameScratch& sc, int out_w) {
+  const ga3c::ResampleTable& t = sc.th;
+  sc.hbase.clear(); sc.hweight.clear(); sc.hsel.clear();
+  if (out_w % 4) return;
+  const int groups = out_w / 4;
+  std::vector<int32_t> base((size_t)groups), weight((size_t)groups * t.ksize * 4, 0);
+  std::vector<uint8_t> sel((size_t)groups * t.ksize * 16, 0x80);
+  for (int g = 0; g < groups; ++g) {
+    base[g] = t.bounds[(size_t)(4 * g) * 2];
+    for (int q = 0; q < 4; ++q) {
+      const int xx = 4 * g + q, xmin = t.bounds[(size_t)xx * 2], n = t.bounds[(size_t)xx * 2 + 1];
+      if (xmin < base[g] || xmin + n - base[g] > 16) return;          // does not fit one 16-byte window: scalar pass
+      for (int k = 0; k < n; ++k) {
+        sel[((size_t)g * t.ksize + k) * 16 + 4 * q] = (uint8_t)(xmin - base[g] + k);
+        weight[((size_t)g * t.ksize + k) * 4 + q] = t.kk[(size_t)xx * t.ksize + k];
+      }
+    }
+  }
+  sc.hbase.swap(base); sc.hweight.swap(weight); sc.hsel.swap(sel);
+}
+
+#define GA3C_FE_LOOPS(SUFFIX, ATTR)                                                                                    \
+  ATTR void fe_gray##SUFFIX(const uint8_t* rgb, size_t npx, int channels, double* gray, double* lo, double* hi) {      \
+    double mn = 1e300, mx = -1e300;                                                                                    \
+    size_t i = 0;                                                                                                      \
+    if (channels == 3) {        /* 4 pixels = 12 contiguous bytes per turn: independent chains, min / max folded late */ \
+      for (; i + 4 <= npx; i += 4) {                                                                                   \
+        const uint8_t* px = rgb + i * 3;                                                                               \
+        const double g0 = std::fma((double)px[2], 0.114, std::fma((double)px[1], 0.587, (double)px[0] * 0.299));       \
+        const double g1 = std::fma((double)px[5], 0.114, std::fma((double)px[4], 0.587, (double)px[3] * 0.299));       \
+        const double g2 = std::fma((double)px[8], 0.114, std::fma((double)px[7], 0.587, (double)px[6] * 0.299));       \
+        const double g3 = std::fma((double)px[11], 0.114, std::fma((double)px[10], 0.587, (double)px[9] * 0.299));     \
+        gray[i] = g0; gray[i + 1] = g1; gray[i + 2] = g2; gray[i + 3] = g3;                                            \
+        const double a = g0 < g1 ? g0 : g1, b = g2 < g3 ? g2 : g3, c = g0 > g1 ? g0 : g1, d = g2 > g3 ? g2 : g3;       \
+        const double lo4 = a < b ? a : b, hi4 = c > d ? c : d;                                                         \
+        mn = lo4 < mn ? lo4 : mn;                                                                                      \
+        mx = hi4 > mx ? hi4 : mx;                                                                                      \
+      }                                                                                                                \
+    }                                                                                                                  \
+    for (; i < npx; ++i) {                                                                                             \
+      const uint8_t* px = rgb + i * channels;                                                                          \
+      /* np.dot's order on a [H, W, 3] frame: fused multiply-adds, left to right */                                    \
+      const double g = std::fma((double)px[2], 0.114, std::fma((double)px[1], 0.587, (double)px[0] * 0.299));          \
+      gray[i] = g;                                                                                                     \
+      mn = g < mn ? g : mn;                                                                                            \
+      mx = g > mx ? g : mx;                                                                                            \
+    }                                                                                                                  \
+    *lo = mn;                                                                                                          \
+    *hi = mx;                                                                                                          \
+  }                                                                                                                    \
+  ATTR void fe_bytescale##SUFFIX(const double* gray, size_t npx, double cmin, double scale, uint8_t* img) {            \
+    for (size_t i = 0; i < npx; ++i) {                                                                                 \
+      const double d = gray[i] - cmin;         /* separately rounded subtract and multiply, as numpy evaluates them */ \
+      const double t = d * scale;                                                                                      \
+      const double c = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);                                                        \
+      img[i] = (uint8_t)(int)(c + 0.5);                                                                                \
+    }                                                                                                                  \
+  }                                                                                                                    \
+  ATTR void fe_vpass##SUFFIX(const uint8_t* src, int cur_w, const ga3c::ResampleTable& t, uint8_t* plane) {            \
+    std::vector<int32_t> acc((size_t)cur_w);                                                                           \
+    for (int yy = 0; yy < t.out_size; ++yy) {                                                                          \
+      const int ymin = t.bounds[(size_t)yy * 2], n = t.bounds[(size_t)yy * 2 + 1];                                     \
+      for (int x = 0; x < cur_w; ++x) acc[x] = 1 << (ga3c::RESAMPLE_PRECISION_BITS - 1);                               \
+      for (int k = 0; k < n; ++k) {                                                                                    \
+        const uint8_t* row = src + (size_t)(ymin + k) * cur_w;                                                         \
+        const int32_t c = t.kk[(size_t)yy * t.ksize + k];                                                              \
+        for (int x = 0; x < cur_w; ++x) acc[x] += (int32_t)row[x] * c;                                                 \
+      }                                                                                                                \
+      for (int x = 0; x < cur_w; ++x) {                                                                                \
+        const int32_t v = acc[x] >> ga3c::RESAMPLE_PRECISION_BITS;                                                     \
+        plane[(size_t)yy * cur_w + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));                                    \
+      }                                                                                                                \
+    }                                                                                                                  \
+  }
+
+GA3C_FE_LOOPS(_base, )
+#if defined(__x86_64__)
+GA3C_FE_LOOPS(_auto, __attribute__((target("avx2,fma"))))
+
+// hand-vectorised forms of the two per-pixel loops (4 pixels per step): same operations in the same order per pixel
+__attribute__((target("avx2,fma"))) void fe_gray_v3(const uint8_t* rgb, size_t npx, int channels, double* gray, double* lo,
+                                                    double* hi) {
+  size_t i = 0;
+  __m256d vmn = _mm256_set1_pd(1e300), vmx = _mm256_set1_pd(-1e300);
+  if (channels == 3 && npx >= 8) {
+    const __m128i sr = _mm_setr_epi8(0, -1, -1, -1, 3, -1, -1, -1, 6, -1, -1, -1, 9, -1, -1, -1);
+    const __m128i sg = _mm_setr_epi8(1, -1, -1, -1, 4, -1, -1, -1, 7, -1, -1, -1, 10, -1, -1, -1);
+    const __m128i sb = _mm_setr_epi8(2, -1, -1, -1, 5, -1, -1, -1, 8, -1, -1, -1, 11, -1, -1, -1);
+    const __m256d c0 = _mm256_set1_pd(0.299), c1 = _mm256_set1_pd(0.587), c2 = _mm256_set1_pd(0.114);
+    for (; i + 8 <= npx; i += 4) {     // the 16-byte load covers 12 pixel bytes + 4 more: stop two groups early
+      const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(rgb + i * 3));
+      const __m256d r = _mm256_cvtepi32_pd(_mm_shuffle_epi8(v, sr));
+      const __m256d g = _mm256_cvtepi32_pd(_mm_shuffle_epi8(v, sg));
+      const __m256d b = _mm256_cvtepi32_pd(_mm_shuffle_epi8(v, sb));
+      const __m256d y = _mm256_fmadd_pd(b, c2, _mm256_fmadd_pd(g, c1, _mm256_mul_pd(r, c0)));
+      _mm256_storeu_pd(gray + i, y);
+      vmn = _mm256_min_pd(vmn, y);
+      vmx = _mm256_max_pd(vmx, y);
+    }
+  }
+  double t[4], mn, mx;
+  _mm256_storeu_pd(t, vmn);
+  mn = std::min(std::min(t[0], t[1]), std::min(t[2], t[3]));
+  _mm256_storeu_pd(t, vmx);
+  mx = std::max(std::max(t[0], t[1]), std::max(t[2], t[3]));
+  for (; i < npx; ++i) {
+    const uint8_t* px = rgb + i * channels;
+    const double g = std::fma((double)px[2], 0.114, std::fma((double)px[1], 0.587, (double)px[0] * 0.299));
+    gray[i] = g;
+    mn = g < mn ? g : mn;
+    mx = g > mx ? g : mx;
+  }
+  *lo = mn;
+  *hi = mx;
+}
+
+__attribute__((target("avx2,fma"))) void fe_bytescale_v3(const double* gray, size_t npx, double cmin, double scale, uint8_t* img) {
+  size_t i = 0;
+  const __m256d vmin = _mm256_set1_pd(cmin), vs = _mm256_set1_pd(scale), z = _mm256_setzero_pd(), top = _mm256_set1_pd(255.0),
+                half = _mm256_set1_pd(0.5);
+  for (; i + 4 <= npx; i += 4) {
+    __m256d t = _mm256_mul_pd(_mm256_sub_pd(_mm256_loadu_pd(gray + i), vmin), vs);   // two roundings, as numpy
+    t = _mm256_min_pd(_mm256_max_pd(t, z), top);
+    const __m128i q = _mm256_cvttpd_epi32(_mm256_add_pd(t, half));                    // truncation, values in 0..255
+    const __m128i b = _mm_packus_epi16(_mm_packus_epi32(q, q), q);
+    const int w = _mm_cvtsi128_si32(b);
+    memcpy(img + i, &w, 4);
+  }
+  for (; i < npx; ++i) {
+    const double d = gray[i] - cmin;
+    const double t = d * scale;
+    const double c = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
+    img[i] = (uint8_t)(int)(c + 0.5);
+  }
+}
+
+// horizontal pass with the plan of build_hpass_plan: per 4 outputs one 16-byte load, then per tap a shuffle, a 32-bit
+// multiply and an add -- the integer arithmetic of the scalar loop, lane by lane
+__attribute__((target("avx2,fma"))) void fe_hpass_v3(const uint8_t* src, int height, int width, int out_w, const FrameScratch& sc,
+                                                     uint8_t* dst) {
+  const int groups = out_w / 4, ks = sc.th.ksize;
+  const __m128i half = _mm_set1_epi32(1 << (ga3c::RESAMPLE_PRECISION_BITS - 1));
+  for (int y = 0; y < height; ++y) {
+    const uint8_t* row = src + (size_t)y * width;
+    uint8_t* out = dst + (size_t)y * out_w;
+    for (int g = 0; g < groups; ++g) {
+      const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(row + sc.hbase[g]));   // buffers carry 16 spare bytes
+      __m128i acc = half;
+      for (int k = 0; k < ks; ++k) {
+        const __m128i sel = _mm_loadu_si128(reinterpret_cast<const __m128i*>(&sc.hsel[((size_t)g * ks + k) * 16]));
+        const __m128i w = _mm_loadu_si128(reinterpret_cast<const __m128i*>(&sc.hweight[((size_t)g * ks + k) * 4]));
+        acc = _mm_add_epi32(acc, _mm_mullo_epi32(_mm_shuffle_epi8(v, sel), w));
+      }
+      acc = _mm_srai_epi32(acc, ga3c::RESAMPLE_PRECISION_BITS);
+      const __m128i b = _mm_packus_epi16(_mm_packus_epi32(acc, acc), acc);     // saturating: clip8
+      const int w4 = _mm_cvtsi128_si32(b);
+      memcpy(out + 4 * g, &w4, 4);
+    }
+  }
+}
+#endif
+#undef GA3C_FE_LOOPS
+
+bool cpu_has_v3() {
+#if defined(__x86_64__)
+  static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+  return ok;
+#else
+  return false;
+#endif
+}
+
+}  // namespace
+
 int ga3c_frame_preprocess(const uint8_t* rgb, int32_t height, int32_t width, int32_t channels, int32_t out_h,
                           int32_t out_w, uint8_t* plane) {
   if (!rgb || !plane || height < 1 || width < 1 || channels < 3 || out_h < 1 || out_w < 1)
     return fail(GA3C_H_EINVAL, "bad argument");
+  thread_local FrameScratch sc;
   const size_t npx = (size_t)height * width;
-  std::vector<double> gray(npx);
-  double cmin = 0.0, cmax = 0.0;
-  for (size_t i = 0; i < npx; ++i) {
-    const uint8_t* px = rgb + i * channels;
-    // np.dot's order on a [H, W, 3] frame: fused multiply-adds, left to right (oracle/frame_frontend.py: rgb2gray)
-    const double g = std::fma((double)px[2], 0.114, std::fma((double)px[1], 0.587, (double)px[0] * 0.299));
-    gray[i] = g;
-    if (i == 0 || g < cmin) cmin = g;
-    if (i == 0 || g > cmax) cmax = g;
+  if (sc.gray.size() < npx) { sc.gray.resize(npx); sc.img.assign(npx + 16, 0); }   // + 16: the vector pass loads whole windows
+  if (sc.th.in_size != width || sc.th.out_size != out_w) {
+    sc.th = ga3c::make_bilinear_table(width, out_w);
+    build_hpass_plan(sc, out_w);
   }
+  if (sc.tv.in_size != height || sc.tv.out_size != out_h) sc.tv = ga3c::make_bilinear_table(height, out_h);
+  const bool v3 = cpu_has_v3();
+  double cmin, cmax;
+#if defined(__x86_64__)
+  if (v3) fe_gray_v3(rgb, npx, channels, sc.gray.data(), &cmin, &cmax); else
+#endif
+    fe_gray_base(rgb, npx, channels, sc.gray.data(), &cmin, &cmax);
   double cscale = cmax - cmin;
   if (cscale == 0.0) cscale = 1.0;
   const double scale = 255.0 / cscale;
-  std::vector<uint8_t> img(npx);
-  for (size_t i = 0; i < npx; ++i) {
-    volatile double t = gray[i] - cmin;   // separately rounded subtract and multiply, as numpy evaluates them
-    t = t * scale;
-    double c = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
-    img[i] = (uint8_t)(c + 0.5);
-  }
-  const int half = 1 << (ga3c::RESAMPLE_PRECISION_BITS - 1);
-  auto clip8 = [](int32_t acc) {
-    const int32_t v = acc >> ga3c::RESAMPLE_PRECISION_BITS;
-    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-  };
-  std::vector<uint8_t> tmp;
-  const uint8_t* src = img.data();
+#if defined(__x86_64__)
+  if (v3) fe_bytescale_v3(sc.gray.data(), npx, cmin, scale, sc.img.data()); else
+#endif
+    fe_bytescale_base(sc.gray.data(), npx, cmin, scale, sc.img.data());
+  const uint8_t* src = sc.img.data();
   int cur_w = width;
-  if (width != out_w) {   // horizontal pass
-    const ga3c::ResampleTable t = ga3c::make_bilinear_table(width, out_w);
-    tmp.resize((size_t)height * out_w);
-    for (int y = 0; y < height; ++y)
+  if (width != out_w) {   // horizontal pass: few taps per output, not worth vectorising
+    const ga3c::ResampleTable& t = sc.th;
+    if (sc.tmp.size() < (size_t)height * out_w) sc.tmp.resize((size_t)height * out_w);
+#if defined(__x86_64__)
+    if (v3 && !sc.hbase.empty()) fe_hpass_v3(src, height, width, out_w, sc, sc.tmp.data()); else
+#endif
+    for (int y = 0; y < height; ++y) {
+      const uint8_t* row = src + (size_t)y * width;
+      uint8_t* dst = sc.tmp.data() + (size_t)y * out_w;
       for (int xx = 0; xx < out_w; ++xx) {
         const int xmin = t.bounds[(size_t)xx * 2], n = t.bounds[(size_t)xx * 2 + 1];
-        int32_t acc = half;
-        for (int x = 0; x < n; ++x) acc += (int32_t)src[(size_t)y * width + xmin + x] * t.kk[(size_t)xx * t.ksize + x];
-        tmp[(size_t)y * out_w + xx] = clip8(acc);
-      }
-    src = tmp.data();
-    cur_w = out_w;
-  }
-  if (height != out_h) {  // vertical pass
-    const ga3c::ResampleTable t = ga3c::make_bilinear_table(height, out_h);
-    for (int yy = 0; yy < out_h; ++yy) {
-      const int ymin = t.bounds[(size_t)yy * 2], n = t.bounds[(size_t)yy * 2 + 1];
-      for (int x = 0; x < cur_w; ++x) {
-        int32_t acc = half;
-        for (int k = 0; k < n; ++k) acc += (int32_t)src[(size_t)(ymin + k) * cur_w + x] * t.kk[(size_t)yy * t.ksize + k];
-        plane[(size_t)yy * cur_w + x] = clip8(acc);
+        const int32_t* kk = &t.kk[(size_t)xx * t.ksize];
+        int32_t acc = 1 << (ga3c::RESAMPLE_PRECISION_BITS - 1);
+        if (t.ksize == 5 && xmin + 5 <= width) {   // the Atari geometry (160 -> 84): taps past the count are 0
+          acc += (int32_t)row[xmin] * kk[0] + (int32_t)row[xmin + 1] * kk[1] + (int32_t)row[xmin + 2] * kk[2] +
+                 (int32_t)row[xmin + 3] * kk[3] + (int32_t)row[xmin + 4] * kk[4];
+        } else {
+          for (int x = 0; x < n; ++x) acc += (int32_t)row[xmin + x] * kk[x];
+        }
+        const int32_t v = acc >> ga3c::RESAMPLE_PRECISION_BITS;
+        dst[xx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
       }
     }
+    src = sc.tmp.data();
+    cur_w = out_w;
+  }
+  if (height != out_h) {  // vertical pass: whole rows at a time
+#if defined(__x86_64__)
+    if (v3) fe_vpass_auto(src, cur_w, sc.tv, plane); else
+#endif
+      fe_vpass_base(src, cur_w, sc.tv, plane);
   } else {
     memcpy(plane, src, (size_t)out_h * cur_w);
   }
