@@ -40,13 +40,13 @@ HBM_PEAK_GBS = 8000.0                                                   # MI355X
 MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
 
 
-def run_engine(model, seconds, agents, B, A, frames="planes"):
+def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2):
     """The whole engine for `seconds`: synthetic agents -> shm transport -> ThreadPredictor / ThreadTrainer -> `model`
     (None = the HIP Network).  Returns rates over the steady window of the run."""
     import threading
     from Config import Config
     from Server import Server
-    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = agents, 2, 2
+    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = agents, predictors, 2
     Config.TRAINING_MIN_BATCH_SIZE = B - 1
     Config.DYNAMIC_SETTINGS, Config.SAVE_MODELS, Config.TENSORBOARD = False, False, False
     Config.PRINT_STATS_FREQUENCY = 10 ** 9
@@ -81,7 +81,7 @@ def run_engine(model, seconds, agents, B, A, frames="planes"):
                       "train_rows_per_step": (fb - fa) / max(sb - sa, 1), "mean_predict_batch": (pb - pa) / max(bb - ba, 1)}
         else:
             steady = dict(whole, train_rows_per_step=srv.frame_counter / max(srv.training_step, 1), mean_predict_batch=None)
-        res = dict(steady, agents=agents, predictors=2, trainers=2, whole_run=whole,
+        res = dict(steady, agents=agents, predictors=predictors, trainers=2, whole_run=whole,
                    native_predictor_loop=bool(native and native[0]))
         if model is None:
             srv.model.close()
@@ -381,12 +381,18 @@ def main():
         # the same engine fed with raw 210x160x3 emulator frames: the reference's front-end in the agents (host) against the
         # HIP front-end with device-resident frame queues and (agent, plane) rollouts
         half = max(4.0, args.e2e_seconds * 0.75)
-        out["e2e"]["raw_frames"] = {
-            mode: {k: r[k] for k in ("predictions_per_sec", "training_steps_per_sec", "mean_predict_batch", "seconds")}
-            for mode, r in ((m, run_engine(None, half, args.e2e_agents, B, A, frames="rgb-" + m)) for m in ("host", "device"))}
-        out["e2e"]["raw_frames"]["note"] = ("synthetic emulator frames; 'host': ga3c_frame_preprocess in every agent process, "
-                                            "states shipped; 'device': raw frames shipped, front-end + frame queues + plane "
-                                            "history on the GPU")
+        keys = ("predictions_per_sec", "training_steps_per_sec", "mean_predict_batch", "seconds", "agents", "predictors")
+        raw = {}
+        for mult, npred in ((1, 2), (2, 4)):
+            raw["agents_x%d" % mult] = {
+                mode: {k: r[k] for k in keys}
+                for mode, r in ((m, run_engine(None, half, mult * args.e2e_agents, B, A, frames="rgb-" + m, predictors=npred))
+                                for m in ("host", "device"))}
+        raw["note"] = ("synthetic emulator frames; 'host': ga3c_frame_preprocess (AVX2) in every agent process, states shipped, "
+                       "~65 us of agent CPU per step; 'device': raw frames shipped, front-end + frame queues + plane history on "
+                       "the GPU, ~27 us of agent CPU per step -- the host path is ahead while the box's CPU share lasts and "
+                       "falls behind once the agents saturate it")
+        out["e2e"]["raw_frames"] = raw
         if cpu_theta is not None:      # the same harness with the oracle's C port as the model: the CPU path beside it
             import ga3c_oracle_cport as oc
             oc.lib().ga3c_oc_set_threads(4)       # 2 predictor + 2 trainer threads call in concurrently: 4 x 4 = the 16-core share
