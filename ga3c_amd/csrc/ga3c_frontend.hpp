@@ -99,15 +99,14 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
       fe_load4<C>(src + (size_t)grp * 4 * C, gray[j]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        lo = gray[j][q] < lo ? gray[j][q] : lo;
-        hi = gray[j][q] > hi ? gray[j][q] : hi;
+        lo = fmin(lo, gray[j][q]);
+        hi = fmax(hi, gray[j][q]);
       }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
-    const double l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-    lo = l2 < lo ? l2 : lo;
-    hi = h2 > hi ? h2 : hi;
+    lo = fmin(lo, __shfl_xor(lo, o));
+    hi = fmax(hi, __shfl_xor(hi, o));
   }
   if ((tid & 63) == 0) {
     red_min[tid >> 6] = lo;
@@ -116,9 +115,10 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   __syncthreads();
   lo = red_min[0];
   hi = red_max[0];
+#pragma unroll
   for (int w = 1; w < FE_THREADS / 64; ++w) {
-    lo = red_min[w] < lo ? red_min[w] : lo;
-    hi = red_max[w] > hi ? red_max[w] : hi;
+    lo = fmin(lo, red_min[w]);
+    hi = fmax(hi, red_max[w]);
   }
   double cscale = __dsub_rn(hi, lo);
   if (cscale == 0.0) cscale = 1.0;
@@ -132,9 +132,12 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
       uint32_t packed = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        double t = __dmul_rn(__dsub_rn(gray[j][q], lo), scale);
-        t = t < 0.0 ? 0.0 : (t > 255.0 ? 255.0 : t);
-        packed |= (uint32_t)(int)__dadd_rn(t, 0.5) << (8 * q);
+        // numpy clips to [0, 255], adds .5 and truncates; inside that range adding first and clamping the integer is the
+        // same value, outside it both give 0 or 255 -- one integer clamp instead of two f64 compare / select pairs
+        const double t = __dmul_rn(__dsub_rn(gray[j][q], lo), scale);
+        int v = (int)__dadd_rn(t, 0.5);
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        packed |= (uint32_t)v << (8 * q);
       }
       reinterpret_cast<uint32_t*>(g8)[grp] = packed;
     }
@@ -172,9 +175,11 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
           const uint32_t b03 = __funnelshift_r(w0, w1, sh), b47 = __funnelshift_r(w1, w2, sh);
           int32_t acc = 1 << (FE_PRECISION_BITS - 1);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            acc += (int32_t)((b03 >> (8 * k)) & 255u) * tap[q][k];
-            acc += (int32_t)((b47 >> (8 * k)) & 255u) * tap[q][4 + k];
+          for (int k = 0; k < 4; ++k) acc += (int32_t)((b03 >> (8 * k)) & 255u) * tap[q][k];
+          acc += (int32_t)(b47 & 255u) * tap[q][4];
+          if (a.hks > 5) {                                   // uniform: 160 -> 84 has 5 taps per output
+#pragma unroll
+            for (int k = 1; k < 4; ++k) acc += (int32_t)((b47 >> (8 * k)) & 255u) * tap[q][4 + k];
           }
           packed |= fe_clip8(acc) << (8 * q);
         }
