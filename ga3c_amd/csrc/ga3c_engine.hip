@@ -1054,7 +1054,7 @@ int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, in
   if (npx % 4 || npx > (int64_t)4 * FE_MAXG * FE_THREADS)
     return fail(GA3C_EINVAL, "frames: height*width must be a multiple of 4 and at most %d", 4 * FE_MAXG * FE_THREADS);
   if (th.ksize > FE_MAXK) return fail(GA3C_EINVAL, "frames: width %d needs %d taps per output, the kernel holds %d", width, th.ksize, FE_MAXK);
-  f.lds = frontend_lds_bytes(height, width, IMG, IMG, f.vks);
+  f.lds = frontend_lds_bytes(height, width, IMG, IMG, f.hks, f.vks);
   if (f.lds > 150 * 1024) return fail(GA3C_EINVAL, "frames: a %dx%d frame does not fit the kernel's LDS plan", height, width);
   for (const void* fn : {reinterpret_cast<const void*>(&frame_frontend_kernel<3>),
                          reinterpret_cast<const void*>(&frame_frontend_kernel<4>)})

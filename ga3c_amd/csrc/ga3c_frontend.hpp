@@ -77,16 +77,20 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   const int tid = threadIdx.x, f = blockIdx.x;
   const int npx = a.H * a.W, ngrp = npx / 4;            // npx % 4 == 0 (checked on the host)
   const int nout = a.OH * a.OW;
-  // LDS map: [vertical tables][g8: npx][tmp: H*OW]
+  // LDS map: [resample tables][g8: npx][tmp: H*OW].  The tables are fetched here, under the frame loads' latency.
   int32_t* t_vb = reinterpret_cast<int32_t*>(fe_lds);
   int32_t* t_vk = t_vb + a.OH * 2;
-  const int tab_bytes = (a.OH * (2 + a.vks) * 4 + 15) & ~15;
+  int32_t* t_hb = t_vk + a.OH * a.vks;
+  int32_t* t_hk = t_hb + a.OW * 2;
+  const int tab_bytes = ((a.OH * (2 + a.vks) + a.OW * (2 + a.hks)) * 4 + 15) & ~15;
   uint8_t* g8 = fe_lds + tab_bytes;
   uint8_t* tmp = g8 + ((npx + 15) & ~15);
   __shared__ double red_min[FE_THREADS / 64], red_max[FE_THREADS / 64];
 
   for (int i = tid; i < a.OH * 2; i += FE_THREADS) t_vb[i] = a.vb[i];
   for (int i = tid; i < a.OH * a.vks; i += FE_THREADS) t_vk[i] = a.vk[i];
+  for (int i = tid; i < a.OW * 2; i += FE_THREADS) t_hb[i] = a.hb[i];
+  for (int i = tid; i < a.OW * a.hks; i += FE_THREADS) t_hk[i] = a.hk[i];
 
   // ---- pass 1: the frame's bytes -> f64 gray in registers; per-frame min / max
   const uint8_t* src = a.src_off ? a.rgb + a.src_off[f] : a.rgb + (size_t)f * npx * C;
@@ -155,10 +159,10 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
     int xmin[4], tap[4][FE_MAXK];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int xx = grp * 4 + q, n = a.hb[xx * 2 + 1];
-      xmin[q] = a.hb[xx * 2];
+      const int xx = grp * 4 + q, n = t_hb[xx * 2 + 1];
+      xmin[q] = t_hb[xx * 2];
 #pragma unroll
-      for (int k = 0; k < FE_MAXK; ++k) tap[q][k] = (k < a.hks && k < n) ? a.hk[xx * a.hks + k] : 0;
+      for (int k = 0; k < FE_MAXK; ++k) tap[q][k] = (k < a.hks && k < n) ? t_hk[xx * a.hks + k] : 0;
     }
     if (y0 < lanes_y) {
       for (int y = y0; y < a.H; y += lanes_y) {
@@ -256,8 +260,8 @@ __global__ __launch_bounds__(256) void gather_history_kernel(const uint8_t* __re
 }
 
 // bytes of dynamic LDS the kernel needs for a frame geometry
-inline size_t frontend_lds_bytes(int H, int W, int OH, int OW, int vks) {
-  const size_t tab = ((size_t)OH * (2 + vks) * 4 + 15) & ~(size_t)15;
+inline size_t frontend_lds_bytes(int H, int W, int OH, int OW, int hks, int vks) {
+  const size_t tab = ((size_t)(OH * (2 + vks) + OW * (2 + hks)) * 4 + 15) & ~(size_t)15;
   const size_t g8 = ((size_t)H * W + 15) & ~(size_t)15;
   return tab + g8 + (((size_t)H * OW + 15) & ~(size_t)15);
 }
