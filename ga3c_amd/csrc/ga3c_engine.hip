@@ -102,7 +102,11 @@ struct TrainLane {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
-int dense_ks(int B) { return B <= 256 ? 22 : (B <= 1024 ? 11 : 2); }
+// K slices of dense1_fwd.  Its grid is (row blocks) x (2 column halves) x (slices), every slice a partial slab that
+// `heads` reads back; the 242 K steps are cut as evenly as integers allow, so the count need not divide 242.  Measured
+// on the MI355X (profiles/README.md): 16 slices give 256 / 512 / 512 workgroups at batch 128 / 256 / 512 -- whole rounds
+// on the 256 CUs -- and beat the former 22 / 22 / 11 by 5 / 8 / 20 %; at batch 1024 8 slices (512 workgroups) beat 11.
+int dense_ks(int B) { return B <= 512 ? 16 : (B <= 1024 ? 8 : 4); }
 }  // namespace
 
 // Frame front-end state (ga3c_net_frames_*): resample tables, one 4-deep frame queue per agent, staging.
@@ -181,7 +185,7 @@ int dmalloc(float** p, size_t floats) {
 int alloc_fwd(Fwd& f, int maxB, int A) {
   size_t part = 0;
   for (int b : {maxB < 256 ? maxB : 256, maxB < 1024 ? maxB : 1024, maxB}) {
-    const size_t need = (size_t)dense_ks(b) * b * HID;
+    const size_t need = (size_t)22 * b * HID;   // dense_ks() <= 22
     if (need > part) part = need;
   }
   CHK(dmalloc(&f.x, (size_t)maxB * XS));
@@ -237,10 +241,10 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   const int ks = dense_ks(B);
   if (B <= 256)
     hipLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
-                       f.part, B, ks, KSTEPS_DENSE / ks);
+                       f.part, B, ks, -1);
   else
     hipLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
-                       f.part, B, ks, KSTEPS_DENSE / ks);
+                       f.part, B, ks, -1);
   HeadArgs h;
   memset(&h, 0, sizeof h);
   h.part = f.part; h.ks = ks; h.B = B; h.A = A;
@@ -1489,10 +1493,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       const int ks = dense_ks(B);
       if (B <= 256)
         TL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), t.f.n2, net->theta_pk[net->latest], t.f.part, B, ks,
-           KSTEPS_DENSE / ks);
+           -1);
       else
         TL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), t.f.n2, net->theta_pk[net->latest], t.f.part, B, ks,
-           KSTEPS_DENSE / ks);
+           -1);
     } else if (k == "conv1_dw") {
       TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {

@@ -460,7 +460,10 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
   f32x4 acc[MT][2];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) acc[mi][0] = acc[mi][1] = zero4();
-  const int s0 = ks * steps_per_slice, s1 = s0 + steps_per_slice;
+  // slice ks of ks_total: the 242 K steps are cut as evenly as integers allow (steps_per_slice < 0), so that the slice
+  // count can be picked to fill whole rounds of workgroups on the 256 CUs rather than to divide 242
+  const int s0 = steps_per_slice > 0 ? ks * steps_per_slice : (ks * KSTEPS_DENSE) / ks_total;
+  const int s1 = steps_per_slice > 0 ? s0 + steps_per_slice : ((ks + 1) * KSTEPS_DENSE) / ks_total;
   f32x4 a[MT], w0 = ld4(w0p + (size_t)s0 * HID * 16), w1 = ld4(w1p + (size_t)s0 * HID * 16);
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) a[mi] = v[mi] ? ld4(ap[mi] + 16 * s0) : zero4();
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   f32x4 d = ld4(h.bd + 4 * lane);
   const float* pp = h.part + (size_t)b * HID + 4 * lane;
   const size_t kstride = (size_t)h.B * HID;
-  {   // dense_ks() picks 22, 11 or 2 slices: all of them in flight at once, summed in slice order
+  {   // dense_ks() picks at most 22 slices: all of them in flight at once, summed in slice order
     f32x4 t[22];
 #pragma unroll
     for (int i = 0; i < 22; ++i) t[i] = i < h.ks ? ld4(pp + (size_t)i * kstride) : zero4();
