@@ -107,6 +107,9 @@ struct TrainLane {
 // on the MI355X (profiles/README.md): 16 slices give 256 / 512 / 512 workgroups at batch 128 / 256 / 512 -- whole rounds
 // on the 256 CUs -- and beat the former 22 / 22 / 11 by 5 / 8 / 20 %; at batch 1024 8 slices (512 workgroups) beat 11.
 int dense_ks(int B) { return B <= 512 ? 16 : (B <= 1024 ? 8 : 4); }
+// 16-row tiles per wave in dense1_dx (weight fragments are reused across them).  Measured, dense1_bwd per launch:
+// batch 256: 30.4 / 23.3 / 26.3 us with 4 / 2 / 1 tiles; batch 512: 39.6 / 41.4 / 46.3; batch 1024: 71.6 / 76.3 / 87.0.
+int dense_dx_mt(int B) { return B > 384 ? 4 : (B > 192 ? 2 : 1); }
 }  // namespace
 
 // Frame front-end state (ga3c_net_frames_*): resample tables, one 4-deep frame queue per agent, staging.
@@ -273,7 +276,7 @@ int launch_backward(ga3c_net* net, TrainLane& t, const float* th, int B) {
     Dense1BwdArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
     d.hb = hb; d.dw_gx = FLAT / 32 + A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
-    d.dx_mt = B > 192 ? 4 : 1;
+    d.dx_mt = dense_dx_mt(B);
     const int dx_blocks = d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4);
     hipLaunchKernelGGL(dense1_bwd_kernel, dim3(d.dw_blocks + dx_blocks), dim3(256), 0, st, d);
   }
@@ -1516,7 +1519,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.hb.B = B; d.hb.A = net->A; d.hb.d1 = t.f.d1; d.hb.dz = t.dz; d.hb.dv = t.dv; d.hb.lossrow = t.lossrow;
       d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
       d.dw_gx = FLAT / 32 + net->A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
-      d.dx_mt = B > 192 ? 4 : 1;
+      d.dx_mt = dense_dx_mt(B);
       TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4)), d);
     } else if (k == "conv2_bwd") {
       Conv2BwdArgs c;

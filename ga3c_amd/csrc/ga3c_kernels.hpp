@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(256) void dense1_bwd_kernel(Dense1BwdArgs a) {
   else {
     const int j = id - a.dw_blocks;
     if (a.dx_mt == 4) dense1_dx_body<4>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
+    else if (a.dx_mt == 2) dense1_dx_body<2>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
     else dense1_dx_body<1>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
   }
 }
