@@ -107,6 +107,10 @@ struct TrainLane {
 // on the MI355X (profiles/README.md): 16 slices give 256 / 512 / 512 workgroups at batch 128 / 256 / 512 -- whole rounds
 // on the 256 CUs -- and beat the former 22 / 22 / 11 by 5 / 8 / 20 %; at batch 1024 8 slices (512 workgroups) beat 11.
 int dense_ks(int B) { return B <= 512 ? 16 : (B <= 1024 ? 8 : 4); }
+// conv_stack_fwd puts one 1024-thread workgroup (149.5 KB of LDS) on a CU, two per sample: up to 128 samples are one
+// round on the 256 CUs, sample 129 starts a second one (11.3 us at batch 128, 19.9 us at 132), so above 128 the
+// two-kernel form takes over (train steps/s at 132 rows: 10.3 k fused, 10.8 k split).
+constexpr int FUSED_CONV_MAX_B = 128;
 // 16-row tiles per wave in dense1_dx (weight fragments are reused across them).  Measured, dense1_bwd per launch:
 // batch 256: 30.4 / 23.3 / 26.3 us with 4 / 2 / 1 tiles; batch 512: 39.6 / 41.4 / 46.3; batch 1024: 71.6 / 76.3 / 87.0.
 int dense_dx_mt(int B) { return B > 384 ? 4 : (B > 192 ? 2 : 1); }
@@ -225,8 +229,8 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   const int A = net->A;
   const float* th = net->theta[idx];
   const void* xin = f.src_off ? (const void*)f.src_base : (f.x_u8 ? (const void*)f.xu8 : (const void*)f.x);
-  if (f.src_off && !(net->fused_conv && B <= 160)) return fail(GA3C_ESTATE, "scattered intake needs the fused conv stack");
-  if (net->fused_conv && B <= 160) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
+  if (f.src_off && !(net->fused_conv && B <= FUSED_CONV_MAX_B)) return fail(GA3C_ESTATE, "scattered intake needs the fused conv stack");
+  if (net->fused_conv && B <= FUSED_CONV_MAX_B) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
     const size_t lds = CS_LDS_FLOATS * sizeof(float);
 #define CSTACK(T, U)                                                                                                \
   hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, th + OFF_W1, th + OFF_B1, \
@@ -328,7 +332,7 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
     const bool u8 = mode != STEP_GATHER_F32;
     const uint8_t* base = mode == STEP_QUEUES ? reinterpret_cast<const uint8_t*>(net->fr.stacks) : net->reg_dev;
     L.f.x_u8 = u8;
-    if (net->fused_conv && B <= 160) {
+    if (net->fused_conv && B <= FUSED_CONV_MAX_B) {
       // small batches (every engine batch): the conv stack reads the scattered states itself -- one launch less
       L.f.src_base = base;
       L.f.src_off = L.h_off;
