@@ -106,7 +106,10 @@ struct TrainLane {
 // `heads` reads back; the 242 K steps are cut as evenly as integers allow, so the count need not divide 242.  Measured
 // on the MI355X (profiles/README.md): 16 slices give 256 / 512 / 512 workgroups at batch 128 / 256 / 512 -- whole rounds
 // on the 256 CUs -- and beat the former 22 / 22 / 11 by 5 / 8 / 20 %; at batch 1024 8 slices (512 workgroups) beat 11.
-int dense_ks(int B) { return B <= 512 ? 16 : (B <= 1024 ? 8 : 4); }
+int dense_ks(int B) {
+  if (B > 128 && B <= 176) return 22;   // 9-11 row blocks: 16 slices would leave each XCD 36-44 workgroups for its 32 CUs
+  return B <= 512 ? 16 : (B <= 1024 ? 8 : 4);
+}
 // conv_stack_fwd puts one 1024-thread workgroup (149.5 KB of LDS) on a CU, two per sample: up to 128 samples are one
 // round on the 256 CUs, sample 129 starts a second one (11.3 us at batch 128, 19.9 us at 132), so above 128 the
 // two-kernel form takes over (train steps/s at 132 rows: 10.3 k fused, 10.8 k split).
