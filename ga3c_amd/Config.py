@@ -81,6 +81,8 @@ class Config:
     ZERO_COPY = True                    # GPU gathers states straight from the registered shm transport
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often
     NATIVE_PREDICTOR = True             # ThreadPredictor's loop in native code (ga3c_pq_serve) when ZERO_COPY is on
+    PREDICTION_LINGER_US = 0            # > 0: a predictor holding fewer than PREDICTION_LINGER_BATCH requests after its
+    PREDICTION_LINGER_BATCH = 0         # greedy drain keeps collecting this long (the reference never waits: 0)
     ROLLOUT_SLOTS = 0                   # rollout slots of the transport; 0 = MAX_QUEUE_SIZE (the reference's queue bound)
                                         # plus what the trainers keep while a zero-copy batch fills and trains
     FRAME_SOURCE = 'planes'             # 'planes': synthetic 84x84 uint8 planes; 'rgb': synthetic

@@ -51,6 +51,8 @@ class Server:
             slots = Config.MAX_QUEUE_SIZE + (0 if self.device_frontend else 2 * max(Config.TRAINERS, 2) * per_batch)
         self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
                                              slots, Config.TIME_MAX + 1, row_bytes)
+        if Config.PREDICTION_LINGER_US > 0:
+            self.transport.set_linger(Config.PREDICTION_LINGER_US, Config.PREDICTION_LINGER_BATCH)
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
                                                              self.state_dim)
         if self.dp is not None and hasattr(self.model, "comm_init"):

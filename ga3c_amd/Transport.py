@@ -98,6 +98,9 @@ class Transport:
         rc = self._lib.ga3c_pq_serve(self._h, entry, net_handle, int(u8), int(max_batch), int(slice_ms), C.addressof(stats))
         return nat.check_host(rc, "ga3c_pq_serve")
 
+    def set_linger(self, linger_us, min_batch):
+        nat.check_host(self._lib.ga3c_pq_set_linger(self._h, int(linger_us), int(min_batch)), "ga3c_pq_set_linger")
+
     def serve_frames(self, entry, net_handle, max_batch, slice_ms, stats):
         """One time slice of the native predictor loop for raw-frame requests (ga3c_pq_serve_frames)."""
         rc = self._lib.ga3c_pq_serve_frames(self._h, entry, net_handle, int(max_batch), int(slice_ms), C.addressof(stats))

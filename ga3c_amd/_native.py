@@ -113,6 +113,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),
     "ga3c_frame_preprocess": (C.c_int, [u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, u8p]),
+    "ga3c_pq_set_linger": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ga3c_pq_serve_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_pq_serve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_tq_acquire": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -185,6 +185,8 @@ struct Header {
   int64_t rollouts_off, rollout_stride, ro_returns_off, ro_actions_off, ro_rows_off;
   std::atomic<uint32_t> closed;
   uint32_t pad;
+  std::atomic<int32_t> linger_us;      // ga3c_pq_set_linger: how long a predictor keeps collecting after the first request
+  std::atomic<int32_t> linger_batch;   // ... unless it already holds this many
   Ring req, freeq, readyq;
 };
 
@@ -729,8 +731,28 @@ int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t tim
   if (rc != GA3C_H_OK) return rc;
   int n = 1;
   while (n < max_ids && ring_try_pop(shm->base, &h->req, &ids[n])) ++n;
+  // optional linger (off by default: the reference drains without waiting, ThreadPredictor.py:54-55): keep collecting for
+  // up to linger_us while fewer than linger_batch requests are in hand -- every forward pass has a fixed cost of tens
+  // of microseconds, so a few more rows per pass can be worth a short wait
+  const int32_t lus = h->linger_us.load(std::memory_order_relaxed);
+  if (lus > 0) {
+    int want = h->linger_batch.load(std::memory_order_relaxed);
+    if (want > max_ids) want = max_ids;
+    const int64_t until = now_ns() + (int64_t)lus * 1000;
+    while (n < want && now_ns() < until && !h->closed.load(std::memory_order_acquire)) {
+      if (ring_try_pop(shm->base, &h->req, &ids[n])) ++n;
+      else sched_yield();
+    }
+  }
   std::atomic_thread_fence(std::memory_order_acquire);
   return n;
+}
+
+int ga3c_pq_set_linger(ga3c_shm* shm, int32_t linger_us, int32_t min_batch) {
+  if (!shm || linger_us < 0 || min_batch < 0) return fail(GA3C_H_EINVAL, "bad argument");
+  shm->hdr()->linger_batch.store(min_batch, std::memory_order_relaxed);
+  shm->hdr()->linger_us.store(linger_us, std::memory_order_relaxed);
+  return GA3C_H_OK;
 }
 
 int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* p, const float* v) {

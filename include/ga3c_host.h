@@ -99,6 +99,9 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
  * without waiting up to max_ids; returns the count (0 on timeout). */
 int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t timeout_ms);
 int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* p, const float* v);
+/* Optional linger for pop_batch (and the native loops built on it); 0 / 0 = off = the reference's greedy drain.  With
+ * linger_us > 0 a predictor that holds fewer than min_batch requests after draining keeps polling for up to linger_us. */
+int ga3c_pq_set_linger(ga3c_shm* shm, int32_t linger_us, int32_t min_batch);
 
 /* The whole ThreadPredictor.run loop (ThreadPredictor.py:46-66) in native code, so that a predictor thread holds no
  * interpreter lock between batches: pop_batch -> byte offsets of the popped agents' states -> `predict` (the

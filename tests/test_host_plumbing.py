@@ -343,3 +343,43 @@ def test_native_serve_loop_reports_a_failing_engine(mods):
         assert t.serve(C.cast(failing, C.c_void_p).value, None, 1, 8, 20, st) == -4    # closed
     finally:
         t.close()
+
+
+def test_pop_batch_linger_collects_stragglers_only_when_asked(mods):
+    """Default: the reference's greedy drain (whatever is queued, no waiting).  With ga3c_pq_set_linger a predictor that
+    holds fewer than min_batch requests keeps collecting for up to linger_us."""
+    import threading
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_linger"), 8, 6, 64, 4, 6)
+    ids = np.zeros(8, np.uint32)
+    try:
+        def late(agents, delay):
+            time.sleep(delay)
+            for a in agents:
+                t.submit(a)
+
+        t.submit(0)
+        th = threading.Thread(target=late, args=([1, 2], 0.02))
+        th.start()
+        assert t.pop_batch(ids, 1000) == 1 and ids[0] == 0                   # greedy: agents 1, 2 are not waited for
+        th.join()
+        assert t.pop_batch(ids, 1000) == 2
+        t.respond(np.array([0, 1, 2], np.uint32), 3, np.zeros((3, 6), np.float32), np.zeros(3, np.float32))
+        for a in range(3):
+            assert t.wait(a, 1000)[0] == 0
+        t.set_linger(300000, 3)                                              # up to 0.3 s for a batch of 3
+        t.submit(0)
+        th = threading.Thread(target=late, args=([1, 2], 0.02))
+        th.start()
+        t0 = time.time()
+        assert t.pop_batch(ids, 1000) == 3 and sorted(ids[:3].tolist()) == [0, 1, 2]
+        assert time.time() - t0 < 0.25                                       # left as soon as the batch was there
+        th.join()
+        t.respond(np.array([0, 1, 2], np.uint32), 3, np.zeros((3, 6), np.float32), np.zeros(3, np.float32))
+        t.submit(4)
+        t0 = time.time()
+        assert t.pop_batch(ids, 1000) == 1                                   # nobody else comes: gives up after linger_us
+        assert 0.25 < time.time() - t0 < 0.6
+    finally:
+        t.shutdown()
+        t.close()

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--hogwild", action="store_true")
     ap.add_argument("--python-predictor", action="store_true", help="keep ThreadPredictor's loop in Python")
+    ap.add_argument("--linger-us", type=int, default=0)
+    ap.add_argument("--linger-batch", type=int, default=0)
     ap.add_argument("--dynamic", action="store_true", help="ThreadDynamicAdjustment random walk every 2 s (soak test)")
     ap.add_argument("--frames", choices=["planes", "rgb-host", "rgb-device"], default="planes",
                     help="frame source / where the reference's front-end runs (Config.FRAME_SOURCE, Config.FRONTEND)")
@@ -44,6 +46,7 @@ def main():
     Config.DYNAMIC_SETTINGS = bool(args.dynamic)
     Config.DYNAMIC_SETTINGS_STEP_WAIT, Config.DYNAMIC_SETTINGS_INITIAL_WAIT = 2, 2
     Config.PREDICTION_BATCH_SIZE = args.batch
+    Config.PREDICTION_LINGER_US, Config.PREDICTION_LINGER_BATCH = args.linger_us, args.linger_batch
     Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
     Config.TRAIN_MODELS = not args.no_train
     Config.HOGWILD = bool(args.hogwild)
@@ -95,7 +98,7 @@ def main():
     pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
     print(json.dumps({
         "agents": args.agents, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
-        "hogwild": bool(args.hogwild), "frames": args.frames, "native_predictor": not args.python_predictor, "window_s": round(dt, 2), "host_cores": os.cpu_count(),
+        "hogwild": bool(args.hogwild), "frames": args.frames, "linger": [args.linger_us, args.linger_batch], "native_predictor": not args.python_predictor, "window_s": round(dt, 2), "host_cores": os.cpu_count(),
         "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
         "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),
         "predictor_us_per_batch": {k: round((b["loop"][k] - a["loop"][k]) / batches * 1e6, 1) for k in b["loop"]},
