@@ -8,7 +8,7 @@ end adds the knobs this engine needs (devices, transport, return mode).
 
 class Config:
     # ---- what to run -------------------------------------------------------------------------
-    GAME = 'PongDeterministic-v4'       # gym id when gym/ALE is importable; else the synthetic source
+    GAME = 'PongDeterministic-v4'       # gym id, used by FRAME_SOURCE = 'gym' only; the offline sources are synthetic
     PLAY_MODE = False                   # greedy actions, no training, one agent (GA3C.py:46-54)
     TRAIN_MODELS = True
     LOAD_CHECKPOINT = False
@@ -85,7 +85,8 @@ class Config:
     PREDICTION_LINGER_BATCH = 0         # greedy drain keeps collecting this long (the reference never waits: 0)
     ROLLOUT_SLOTS = 0                   # rollout slots of the transport; 0 = MAX_QUEUE_SIZE (the reference's queue bound)
                                         # plus what the trainers keep while a zero-copy batch fills and trains
-    FRAME_SOURCE = 'planes'             # 'planes': synthetic 84x84 uint8 planes; 'rgb': synthetic
+    FRAME_SOURCE = 'planes'             # 'gym': gym.make(GAME) frames (needs gym + ALE, absent offline: untested here);
+                                        # 'planes': synthetic 84x84 uint8 planes; 'rgb': synthetic
                                         # emulator frames FRAME_HEIGHT x FRAME_WIDTH x 3 that go through the reference's
                                         # front-end (Environment.py:52-74: gray, bytescale, bilinear resize, frame queue)
     FRONTEND = 'host'                   # where that front-end runs for 'rgb' frames: 'host' = in the agent process

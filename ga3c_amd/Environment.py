@@ -32,7 +32,21 @@ class Environment:
     only exposes the raw frame (.frame) and the number of frames since reset (.frames_queued): the state lives in HBM."""
 
     def __init__(self, agent_id=0):
-        self.rgb = Config.FRAME_SOURCE == 'rgb'
+        self.gym = None
+        if Config.FRAME_SOURCE == 'gym':
+            # Optional real emulator (Environment.py:41-50, GameManager.py:30-49): gym.make(Config.GAME) supplies the RGB
+            # frames, rewards and `done`; everything downstream (front-end, frame queue, transport) is the 'rgb' path.
+            # gym / ALE are not part of this image, so this branch is untested offline and fails loudly without them.
+            try:
+                import gym
+            except ImportError as e:
+                raise ImportError("Config.FRAME_SOURCE = 'gym' needs the gym package with Atari support (%s); the offline "
+                                  "sources are 'planes' and 'rgb'" % e)
+            self.gym = gym.make(Config.GAME)
+            Config.NUM_ACTIONS = int(self.gym.action_space.n)
+            shape = self.gym.observation_space.shape
+            Config.FRAME_HEIGHT, Config.FRAME_WIDTH = int(shape[0]), int(shape[1])
+        self.rgb = Config.FRAME_SOURCE in ('rgb', 'gym')
         self.on_device = self.rgb and Config.FRONTEND == 'device'
         self.frame = None
         self.frames_queued = 0
@@ -67,14 +81,22 @@ class Environment:
         self.frames_queued = 0
         self._filled = 0
         self._stack32 = np.zeros((Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH), np.uint32)
+        if self.gym is not None:
+            obs = self.gym.reset()
+            self._gym_frame = np.ascontiguousarray(obs[0] if isinstance(obs, tuple) else obs, dtype=np.uint8)
         self._push_frame()
         self.previous_u8 = self.current_u8 = None
 
     def step(self, action):
         self._t += 1
-        draw = self.rng.random()
-        reward = 1.0 if draw < 0.01 else (-1.0 if draw < 0.02 else 0.0)
-        done = self._t >= self.episode_length + self.nb_frames - 1
+        if self.gym is not None:
+            res = self.gym.step(int(action))               # (obs, reward, done, info) or (obs, reward, term, trunc, info)
+            self._gym_frame = np.ascontiguousarray(res[0], dtype=np.uint8)
+            reward, done = float(res[1]), bool(res[2]) or (len(res) == 5 and bool(res[3]))
+        else:
+            draw = self.rng.random()
+            reward = 1.0 if draw < 0.01 else (-1.0 if draw < 0.02 else 0.0)
+            done = self._t >= self.episode_length + self.nb_frames - 1
         self.total_reward += reward
         self._push_frame()
         self.previous_u8 = self.current_u8
@@ -84,6 +106,8 @@ class Environment:
     # ---- internals
     def _emulate(self):
         """The stand-in emulator's next RGB frame."""
+        if self.gym is not None:
+            return self._gym_frame
         fh, fw = Config.FRAME_HEIGHT, Config.FRAME_WIDTH
         if self.frames_queued == 0:
             self._background = np.frombuffer(self.rng.bytes(fh * fw * 3), np.uint8).reshape(fh, fw, 3)

@@ -38,7 +38,7 @@ class Server:
         n_state = Config.IMAGE_HEIGHT * Config.IMAGE_WIDTH * Config.STACKED_FRAMES
         state_bytes = n_state if Config.STATE_TRANSPORT == 'u8' else 4 * n_state
         # device-side frame front-end: slots carry the emulator's raw frame, rollout rows only name their state
-        self.device_frontend = Config.FRAME_SOURCE == 'rgb' and Config.FRONTEND == 'device'
+        self.device_frontend = Config.FRAME_SOURCE in ('rgb', 'gym') and Config.FRONTEND == 'device'
         row_bytes = 0
         if self.device_frontend:
             state_bytes = (Config.FRAME_HEIGHT * Config.FRAME_WIDTH * 3 + 15) // 16 * 16
@@ -229,4 +229,6 @@ class Server:
 
     @staticmethod
     def get_num_action():
+        if Config.FRAME_SOURCE == 'gym':       # as the reference asks a throw-away Environment (Server.py:200-202);
+            Environment()                      # it also fixes NUM_ACTIONS and the frame size in Config
         return int(Config.NUM_ACTIONS)

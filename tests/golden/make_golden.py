@@ -140,6 +140,24 @@ def returns_fork():
                  out_repr=[0.0, 0.5, -3.0, 2.0, 1.0]),
         ],
         convert_data_dtypes=dict(x_="float32", r_="float64", a_="float32", x2_="float32", done_="bool"))
+    # ORACLE-DERIVED cases (oracle/ga3c_oracle.py:accumulate_rewards_fork, NOT recorded from the reference): they pin the C
+    # ABI and the agents' rollout code to the restatement on the shapes the recorded vector does not cover -- T = 1, T = 2,
+    # zero / negative terminal rewards and a TIME_MAX + 1 = 6 row first rollout (ProcessAgent.py:157-162).  Kept under
+    # their own key so the reference-recorded vector above stays distinguishable.
+    import ga3c_oracle as o
+    rng = np.random.default_rng(606)
+    derived = []
+    for rewards, gamma in (([2.5], 0.99), ([7.0, -1.0], 0.5), ([0.0, 0.0, 0.0], 0.99), ([1.0, -1.0, 0.0, 0.0, 1.0, -1.0], 0.99),
+                           ([0.25, 0.0, -0.75, 3.0, 0.0, 0.0], 0.99), (list(rng.normal(size=6)), 0.99),
+                           (list(rng.normal(size=33)), 0.97), ([0.0] * 5 + [-1.0], 0.99)):
+        rewards = [float(r) for r in rewards]
+        for disc, inter in ((True, False), (True, True), (False, False)):
+            out = o.accumulate_rewards_fork(rewards, gamma, rewards[-1], discounting=disc, use_intermediate_reward=inter)
+            derived.append(dict(rewards_hex=[r.hex() for r in rewards], gamma=gamma, terminal_reward_hex=rewards[-1].hex(),
+                                discounting=disc, use_intermediate_reward=inter, out_hex=[float(v).hex() for v in out]))
+    data["oracle_derived_note"] = ("computed by oracle/ga3c_oracle.py, not by the reference: regression vectors for the C ABI "
+                                   "and ProcessAgent (T=1, T=2, zero / negative terminal, TIME_MAX+1 rows)")
+    data["oracle_derived_cases"] = derived
     with open(os.path.join(HERE, "returns_fork.json"), "w") as f:
         json.dump(data, f, indent=1)
 

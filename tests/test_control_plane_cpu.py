@@ -146,3 +146,16 @@ def test_environment_frames_equal_stacked_integer_planes(cfg):
         if t > 3:
             assert np.array_equal(env.previous_u8, np.stack(frames[-5:-1], axis=-1))
         assert done == (t >= 6 + 3)
+
+
+def test_gym_frame_source_fails_loudly_without_gym(monkeypatch):
+    """Config.FRAME_SOURCE = 'gym' (the reference's real emulator, Environment.py:41-50) is an optional hook: gym / ALE are
+    absent offline, and the hook must say so instead of falling back to synthetic frames."""
+    import importlib.util
+    if importlib.util.find_spec("gym") is not None:
+        pytest.skip("gym is installed")
+    from Config import Config
+    from Environment import Environment
+    monkeypatch.setattr(Config, "FRAME_SOURCE", "gym")
+    with pytest.raises(ImportError, match="FRAME_SOURCE = 'gym'"):
+        Environment(0)

@@ -229,9 +229,12 @@ def test_config_branches_match_oracle(cfg):
                              momentum=Config.RMSPROP_MOMENTUM, mom=mom)
         got, want = net.get_arena(0), _flat(params, 6)
         assert np.max(np.abs(got - want)) < 2e-5, np.max(np.abs(got - want))
-        if Config.USE_GRAD_CLIP:     # the clip must actually bite for this test to mean anything
-            gn = np.sqrt(np.sum(np.asarray(g["dense1/b"]) ** 2)) / 256
-            assert gn < Config.GRAD_CLIP_NORM or True
+        if Config.USE_GRAD_CLIP:     # the clip must actually bite for this test to mean anything: at least one tensor scaled
+            _, raw = o.loss_and_grads(params, x.astype(np.float64), y, a.astype(np.float64), 0.02, **kw)
+            scales = {k: Config.GRAD_CLIP_NORM / max(np.sqrt(np.sum(np.asarray(raw[k]) ** 2)) / np.asarray(raw[k]).size,
+                                                     Config.GRAD_CLIP_NORM) for k in o.PARAM_ORDER}
+            assert min(scales.values()) < 0.9, scales
+            assert max(scales.values()) == 1.0, scales     # ... and at least one left alone: both sides of the max()
         if Config.RMSPROP_MOMENTUM:
             assert np.max(np.abs(net.get_arena(2) - _flat(mom, 6))) < 2e-5
     finally:

@@ -64,6 +64,22 @@ def test_returns_c_abi_bit_exact_vs_reference_vectors(mods, golden_dir):
             assert [float(v).hex() for v in got] == [float.fromhex(h).hex() for h in case["out_hex"]]
 
 
+def test_returns_c_abi_bit_exact_vs_oracle_derived_vectors(mods, golden_dir):
+    """T = 1, T = 2, zero / negative terminal rewards, a TIME_MAX + 1 row rollout: vectors computed by the oracle (marked
+    as such in the fixture), compared bit for bit."""
+    tp = mods[1]
+    g = json.load(open(os.path.join(golden_dir, "returns_fork.json")))
+    assert len(g["oracle_derived_cases"]) >= 20
+    for case in g["oracle_derived_cases"]:
+        rewards = [float.fromhex(h) for h in case["rewards_hex"]]
+        got = tp.accumulate_rewards_fork(rewards, case["gamma"], float.fromhex(case["terminal_reward_hex"]),
+                                         case["discounting"], case["use_intermediate_reward"])
+        assert [float(v).hex() for v in got] == case["out_hex"]
+        want = o.accumulate_rewards_fork(rewards, case["gamma"], float.fromhex(case["terminal_reward_hex"]),
+                                         discounting=case["discounting"], use_intermediate_reward=case["use_intermediate_reward"])
+        assert [float(v).hex() for v in want] == case["out_hex"]
+
+
 def test_returns_c_abi_equals_oracle_on_random_rollouts(mods):
     tp = mods[1]
     rng = np.random.default_rng(2)
