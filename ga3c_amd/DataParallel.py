@@ -8,12 +8,24 @@ op = sum by RCCL inside ga3c_net_train / ga3c_net_apply_grads, and every rank ap
 RMSProp step, keeping weights and optimizer slots replicated.  Predictions need no collective: requests
 are sharded across ranks and answered from the local replica.
 
-torch.distributed (gloo) is used only as the launcher-side control plane: it carries the 128-byte RCCL
-id from rank 0 to the others and provides barriers; the data path never touches it.
+Control plane (this file; no torch, no MPI): the launcher -- `python -m torch.distributed.run`, or anything else that
+sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT -- only starts the processes.  Rank 0 listens on an
+ephemeral TCP port of MASTER_ADDR and publishes it in a small rendezvous file named after MASTER_ADDR:MASTER_PORT;
+the other ranks read the file and connect.  Over those sockets travel the 128-byte RCCL id and, while the engine
+runs, rank 0's step credits; the data path (RCCL over xGMI) never touches them.
 """
+import atexit
+import json
 import os
+import select
+import socket
+import struct
+import tempfile
+import time
 
 import numpy as np
+
+RENDEZVOUS_TIMEOUT_S = 300.0
 
 
 def shard_bounds(rows, rank, world):
@@ -27,62 +39,238 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def exchange_comm_id(make_id, rank, nbytes=128):
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("control-plane peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+class Rendezvous:
+    """Star of TCP connections, rank 0 in the middle.  `tag` separates several groups that share one launcher (the RCCL
+    id exchange of bench.py and the engine group of GA3C.py use different tags)."""
+
+    def __init__(self, rank, world, tag="dp", addr=None, port=None, directory=None):
+        self.rank, self.world = int(rank), int(world)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = port or os.environ.get("MASTER_PORT", "29500")
+        directory = directory or os.environ.get("GA3C_DP_DIR", tempfile.gettempdir())
+        self.path = os.path.join(directory, "ga3c_rendezvous_%s_%s_%s.json" % (str(addr).replace(":", "_"), port, tag))
+        self.peers = []          # rank 0: sockets of ranks 1..world-1, in rank order
+        self.up = None           # other ranks: the socket to rank 0
+        if self.world <= 1:
+            return
+        if self.rank == 0:
+            self._serve(addr)
+        else:
+            self._join()
+
+    def _serve(self, addr):
+        token = os.urandom(16).hex()
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        try:
+            srv.bind((addr, 0))
+        except OSError:
+            srv.bind(("127.0.0.1", 0))
+        srv.listen(self.world)
+        tmp = "%s.%d.tmp" % (self.path, os.getpid())
+        with open(tmp, "w") as f:
+            json.dump({"host": srv.getsockname()[0], "port": srv.getsockname()[1], "token": token, "world": self.world}, f)
+        os.replace(tmp, self.path)         # a stale file of an earlier run on the same MASTER_PORT is replaced atomically
+        atexit.register(self._unlink)
+        got = {}
+        srv.settimeout(RENDEZVOUS_TIMEOUT_S)
+        while len(got) < self.world - 1:
+            conn, _ = srv.accept()
+            conn.settimeout(30.0)
+            try:
+                hello = _recv_exact(conn, 36)
+                peer_token, peer_rank = hello[:32].decode(), struct.unpack("<i", hello[32:])[0]
+                if peer_token != token or not (0 < peer_rank < self.world) or peer_rank in got:
+                    conn.close()
+                    continue
+                conn.sendall(b"OK")
+            except (OSError, ConnectionError, UnicodeDecodeError):
+                conn.close()
+                continue
+            conn.settimeout(None)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            got[peer_rank] = conn
+        srv.close()
+        self.peers = [got[r] for r in range(1, self.world)]
+
+    def _join(self):
+        deadline = time.time() + RENDEZVOUS_TIMEOUT_S
+        while True:
+            try:
+                with open(self.path) as f:
+                    info = json.load(f)
+                if info.get("world") != self.world:
+                    raise ValueError("rendezvous file of another job")
+                s = socket.create_connection((info["host"], info["port"]), timeout=5.0)
+                s.sendall(info["token"].encode() + struct.pack("<i", self.rank))
+                if _recv_exact(s, 2) != b"OK":
+                    raise ConnectionError("rendezvous refused")
+                s.settimeout(None)
+                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self.up = s
+                return
+            except (OSError, ValueError, ConnectionError, KeyError):
+                # no file yet, or the file of an earlier run whose rank 0 is gone: rank 0 will (re)write it
+                if time.time() > deadline:
+                    raise TimeoutError("no rendezvous with rank 0 through %s" % self.path)
+                time.sleep(0.05)
+
+    def _unlink(self):
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
+
+    # ---- rank 0 -> everyone
+    def broadcast(self, payload=None, nbytes=0):
+        """Rank 0 passes `payload` (bytes); every rank returns it."""
+        if self.world <= 1:
+            return payload
+        if self.rank == 0:
+            for s in self.peers:
+                s.sendall(payload)
+            return payload
+        return _recv_exact(self.up, nbytes)
+
+    def barrier(self):
+        """Everyone -> rank 0 -> everyone."""
+        if self.world <= 1:
+            return
+        if self.rank == 0:
+            for s in self.peers:
+                _recv_exact(s, 1)
+            for s in self.peers:
+                s.sendall(b"B")
+        else:
+            self.up.sendall(b"b")
+            _recv_exact(self.up, 1)
+
+    def close(self):
+        for s in self.peers + ([self.up] if self.up else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        self.peers, self.up = [], None
+        if self.rank == 0 and self.world > 1:
+            self._unlink()
+
+
+def exchange_comm_id(make_id, rank, nbytes=128, world=None, rendezvous=None):
     """Rank 0 calls make_id() (Network.make_comm_id); every rank returns the same uint8[nbytes] token."""
-    import torch
-    import torch.distributed as dist
-    token = torch.from_numpy(np.ascontiguousarray(make_id(), np.uint8) if rank == 0 else np.zeros(nbytes, np.uint8))
-    dist.broadcast(token, src=0)
-    return token.numpy()
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    rv = rendezvous or Rendezvous(rank, world, tag="rcclid")
+    try:
+        payload = np.ascontiguousarray(make_id(), np.uint8).tobytes() if rank == 0 else None
+        return np.frombuffer(rv.broadcast(payload, nbytes), dtype=np.uint8).copy()
+    finally:
+        if rendezvous is None:
+            rv.barrier()         # rank 0 keeps the file until everybody has the id
+            rv.close()
 
 
-def attach(net, rank, world):
-    """Give `net` an RCCL communicator spanning the process group (call after init_process_group)."""
+def attach(net, rank, world, rendezvous=None):
+    """Give `net` an RCCL communicator spanning the ranks of the launcher."""
     if world > 1:
-        net.comm_init(exchange_comm_id(type(net).make_comm_id, rank), rank, world)
+        net.comm_init(exchange_comm_id(type(net).make_comm_id, rank, world=world, rendezvous=rendezvous), rank, world)
     return net
 
 
+_MSG = struct.Struct("<qqddi4x")          # credit, from_step, lr, beta, stop
+
+
 class EngineGroup:
-    """Lock-step control plane for one Server per GPU (launched with torch.distributed.run).
+    """Lock-step control plane for one Server per GPU.
 
-    Every train step contains an RCCL all-reduce, so all ranks must take exactly the same number of steps.
-    Rank 0 decides when to stop; the decision travels as "stop after global step S" over the gloo group, polled
-    by every rank's main loop (Server.main, 100 Hz).  Trainer threads take a step only while the model's
-    global step is below S, checked under Server.dp_lock, so all ranks end on the same step and none is left
-    waiting inside a collective.
+    Every train step contains an RCCL all-reduce, so all ranks must take exactly the same number of steps, with the
+    same learning rate and beta.  Rank 0 hands out CREDIT: "steps up to G may be taken, and steps after F use (lr,
+    beta)".  A rank never starts a step beyond the credit it has received, so it can never enter a collective that the
+    others will not join; a rank that hears late (its main loop was delayed) stalls until the message arrives instead
+    of hanging.  Stopping = rank 0 no longer extends the credit and says so; every rank leaves when it has taken step
+    G.  The learning rate of a step is a function of the step alone (the messages arrive in order on every rank), so
+    the replicas apply identical updates.
     """
-    MARGIN = 32      # steps between the decision and the stop, so that every rank hears of it in time
+    WINDOW = 64          # least number of steps of credit ahead of rank 0's own step count
 
-    def __init__(self, rank, world, group=None):
-        self.rank, self.world, self.group = rank, world, group
-        self.stop_step = None
+    def __init__(self, rank, world, rendezvous=None):
+        self.rank, self.world = rank, world
+        self.rv = rendezvous if rendezvous is not None else Rendezvous(rank, world, tag="engine")
+        self.credit = 0                  # steps 1..credit may be taken
+        self.stopping = False            # the credit is final
+        self.schedule = []               # (from_step, lr, beta): steps > from_step use lr, beta (until the next entry)
+        self._last_step, self._pace = 0, 0
 
     @classmethod
     def from_env(cls):
-        import torch.distributed as dist
-        rank, local_rank, world = env_rank_world()
+        rank, _, world = env_rank_world()
         if world <= 1:
             return None
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         return cls(rank, world)
 
+    # ---- what Server asks
+    def may_step(self, training_step):
+        return training_step < self.credit
+
+    def finished(self, training_step):
+        return self.stopping and training_step >= self.credit
+
+    def rates_for(self, step):
+        """(lr, beta) of the `step`-th train step (1-based), or None before the first credit arrived."""
+        out = None
+        for from_step, lr, beta in self.schedule:
+            if from_step < step:
+                out = (lr, beta)
+            else:
+                break
+        return out
+
+    def _apply(self, credit, from_step, lr, beta, stop):
+        if not self.schedule or self.schedule[-1][1:] != (lr, beta):
+            self.schedule.append((from_step, lr, beta))
+            if len(self.schedule) > 4096:        # steps before the oldest entries are long past
+                del self.schedule[:2048]
+        self.credit = max(self.credit, credit)
+        self.stopping = self.stopping or bool(stop)
+
     def poll(self, want_stop, current_step, lr, beta):
-        """Collective: call once per main-loop turn on every rank.
-        Returns (agreed stop step or None, learning rate, beta) -- the last two are rank 0's, so that every rank
-        applies the same optimizer step (the anneal of Server.py:168-175 follows rank 0's episode count)."""
-        import torch
-        import torch.distributed as dist
-        msg = torch.zeros(4, dtype=torch.float64)
+        """Call once per main-loop turn (Server.main).  Rank 0 extends the credit and announces it; the other ranks take
+        in whatever has arrived.  Never blocks."""
         if self.rank == 0:
-            if self.stop_step is None and want_stop:
-                self.stop_step = int(current_step) + self.MARGIN
-            msg[0] = 1.0 if self.stop_step is not None else 0.0
-            msg[1] = float(self.stop_step or 0)
-            msg[2], msg[3] = float(lr), float(beta)
-        dist.broadcast(msg, src=0, group=self.group)
-        if msg[0] == 1.0:
-            self.stop_step = int(msg[1])
-        return self.stop_step, float(msg[2]), float(msg[3])
+            if not self.stopping:
+                self._pace = max(self._pace // 2, current_step - self._last_step)      # steps per poll, recent peak
+                self._last_step = current_step
+                credit = max(self.credit, current_step + max(self.WINDOW, 4 * self._pace))
+                if want_stop:
+                    credit = max(self.credit, current_step)     # what is granted stays granted; nothing is added
+                msg = _MSG.pack(credit, self.credit, float(lr), float(beta), 1 if want_stop else 0)
+                self._apply(credit, self.credit, float(lr), float(beta), want_stop)
+                for s in self.rv.peers:
+                    s.sendall(msg)
+        else:
+            while self.rv.up is not None:
+                ready, _, _ = select.select([self.rv.up], [], [], 0)
+                if not ready:
+                    break
+                try:
+                    raw = _recv_exact(self.rv.up, _MSG.size)
+                except ConnectionError:
+                    if not self.stopping:
+                        raise                    # rank 0 is gone without having said stop
+                    self.rv.close()              # rank 0 has left after its last message: nothing more will come
+                    break
+                self._apply(*_MSG.unpack(raw))
+        return self.credit
+
+    def close(self):
+        self.rv.close()

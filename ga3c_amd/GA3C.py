@@ -33,4 +33,8 @@ if __name__ == '__main__':
         Config.RESULTS_FILENAME = 'results_rank%d.txt' % group.rank
         Config.SAVE_MODELS = Config.SAVE_MODELS and group.rank == 0
     from Server import Server
-    Server(engine_group=group).main()
+    try:
+        Server(engine_group=group).main()        # raises (non-zero exit status) if a predictor / trainer thread died
+    finally:
+        if group is not None:
+            group.close()

@@ -43,6 +43,35 @@ def initial_arena(num_actions, seed):
     return np.concatenate(parts)
 
 
+def _default_bucket_limits():
+    """Bucket limits of TensorFlow's default histogram (tensorflow/core/lib/histogram/histogram.cc,
+    InitDefaultBucketsInner: 1e-12 * 1.1^k up to 1e20, mirrored for negatives, 0 in between, DBL_MAX last) -- what
+    tf.summary.histogram (NetworkVP_discrate.py:140-146) files its values under."""
+    pos = []
+    v = 1.0e-12
+    while v < 1.0e20:
+        pos.append(v)
+        v *= 1.1
+    pos.append(np.finfo(np.float64).max)
+    return np.array([-x for x in reversed(pos)] + [0.0] + pos, dtype=np.float64)
+
+
+_BUCKET_LIMITS = _default_bucket_limits()
+
+
+def histogram_proto(values):
+    """The fields of a TensorFlow HistogramProto for `values`: min, max, num, sum, sum_squares and the non-empty run of
+    (bucket_limit, bucket) pairs; a value x is counted in the first bucket whose limit is > x (upper_bound)."""
+    x = np.asarray(values, dtype=np.float64).ravel()
+    idx = np.searchsorted(_BUCKET_LIMITS, x, side="right")
+    counts = np.bincount(idx, minlength=_BUCKET_LIMITS.size)[:_BUCKET_LIMITS.size].astype(np.float64)
+    nz = np.nonzero(counts)[0]
+    lo, hi = (int(nz[0]), int(nz[-1]) + 1) if nz.size else (0, 0)
+    return {"min": np.float64(x.min() if x.size else 0.0), "max": np.float64(x.max() if x.size else 0.0),
+            "num": np.float64(x.size), "sum": np.float64(x.sum()), "sum_squares": np.float64(np.dot(x, x)),
+            "bucket_limit": _BUCKET_LIMITS[lo:hi].copy(), "bucket": counts[lo:hi].copy()}
+
+
 def _device_ordinal(device):
     m = re.search(r"(\d+)\s*$", str(device))
     return int(m.group(1)) if m else 0
@@ -261,6 +290,12 @@ class Network:
                   "ga3c_net_frames_state")
         return (state if depth.value >= Config.STACKED_FRAMES else None), depth.value
 
+    def frames_pushed(self, agent):
+        """Planes pushed into `agent`'s device queue so far (= the sequence number its next plane gets)."""
+        n = C.c_int64()
+        nat.check(self._lib.ga3c_net_frames_pushed(self._h, int(agent), C.byref(n)), "ga3c_net_frames_pushed")
+        return n.value
+
     def predict_frames(self, agents):
         agents = np.ascontiguousarray(agents, dtype=np.int32)
         p = np.empty((agents.size, self.num_actions), dtype=np.float32)
@@ -355,15 +390,65 @@ class Network:
         nat.check(self._lib.ga3c_net_comm_init(self._h, nat.ptr(comm_id, nat.u8p), rank, world), "ga3c_net_comm_init")
 
     # ---- logging / checkpoints -----------------------------------------------------------------
-    def log(self, x, y_r, a, training_step, feed_dict=None):
-        """Scalar summaries of NetworkVP_discrate.py:132-139 appended to logs/<model>/scalars.csv."""
-        if self.last_losses is None:
-            return
+    def evaluate(self, x, y_r, a, offsets=None, frames=None):
+        """Forward + loss of the batch on the current weights, no update: what sess.run(summary_op) evaluates
+        (NetworkVP.py:259-265).  The states are `x` (f32 or uint8 [B,84,84,4]), or rows still lying in the registered
+        transport (`offsets`), or rows named by (agents, plane sequence numbers) (`frames`).
+        Returns (losses[3], d1[B,256], v[B], p[B,A])."""
+        y, a = nat.as_f32(y_r), nat.as_f32(a)
+        b = int(y.shape[0])
+        losses = np.empty(3, np.float32)
+        d1 = np.empty((b, 256), np.float32)
+        v = np.empty(b, np.float32)
+        p = np.empty((b, self.num_actions), np.float32)
+        outs = (nat.ptr(losses), nat.ptr(d1), nat.ptr(v), nat.ptr(p))
+        if frames is not None:
+            agents = np.ascontiguousarray(frames[0], dtype=np.int32)
+            seqs = np.ascontiguousarray(frames[1], dtype=np.int64)
+            nat.check(self._lib.ga3c_net_evaluate_frames(self._h, nat.ptr(agents, nat.i32p), nat.ptr(seqs, nat.i64p), nat.ptr(y),
+                                                         nat.ptr(a), b, float(self.beta), *outs), "ga3c_net_evaluate_frames")
+        elif offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            nat.check(self._lib.ga3c_net_evaluate(self._h, None, None, nat.ptr(offsets, nat.i64p), int(self._transport_u8),
+                                                  nat.ptr(y), nat.ptr(a), b, float(self.beta), *outs), "ga3c_net_evaluate")
+        elif x.dtype == np.uint8:
+            x = np.ascontiguousarray(x)
+            nat.check(self._lib.ga3c_net_evaluate(self._h, None, nat.ptr(x, nat.u8p), None, 0, nat.ptr(y), nat.ptr(a), b,
+                                                  float(self.beta), *outs), "ga3c_net_evaluate")
+        else:
+            x = nat.as_f32(x)
+            nat.check(self._lib.ga3c_net_evaluate(self._h, nat.ptr(x), None, None, 0, nat.ptr(y), nat.ptr(a), b,
+                                                  float(self.beta), *outs), "ga3c_net_evaluate")
+        return losses, d1, v, p
+
+    def log(self, x, y_r, a, training_step, feed_dict=None, offsets=None, frames=None):
+        """The reference's summary_op on the batch it is given (NetworkVP.py:259-265, NetworkVP_discrate.py:132-151):
+        the six scalars (Pcost_advantage, Pcost_entropy, Pcost, Vcost, LearningRate, Beta) appended to
+        logs/<model>/scalars.csv, and the histograms (one per trainable variable, activation_lastdense, activation_v,
+        activation_p) written to logs/<model>/histograms_%08d.npz with the fields of TensorFlow's HistogramProto."""
+        losses, d1, v, p = self.evaluate(x, y_r, a, offsets=offsets, frames=frames)
+        c1, c2, cv = (float(t) for t in losses)
+        theta = self.get_arena(0)
+        hist = {}
+        for name in PARAM_ORDER:
+            off, size = self._offsets[name]
+            hist["weights_%s:0" % name] = histogram_proto(theta[off:off + size])
+        hist["activation_lastdense"] = histogram_proto(d1)
+        hist["activation_v"] = histogram_proto(v)
+        hist["activation_p"] = histogram_proto(p)
+        out = {}
+        for tag, h in hist.items():
+            for field, value in h.items():
+                out["%s/%s" % (tag, field)] = value
         os.makedirs("logs/%s" % self.model_name, exist_ok=True)
-        c1, c2, cv = (float(t) for t in self.last_losses)
-        with self._log_lock, open("logs/%s/scalars.csv" % self.model_name, "a") as f:
-            f.write("%d,%.8g,%.8g,%.8g,%.8g,%.8g,%.8g\n" % (training_step, c1, c2, -(c1 + c2), cv,
-                                                            self.learning_rate, self.beta))
+        with self._log_lock:
+            with open("logs/%s/scalars.csv" % self.model_name, "a") as f:
+                f.write("%d,%.8g,%.8g,%.8g,%.8g,%.8g,%.8g\n" % (training_step, c1, c2, -(c1 + c2), cv,
+                                                                self.learning_rate, self.beta))
+            tmp = "logs/%s/histograms_%08d.tmp.npz" % (self.model_name, training_step)
+            np.savez(tmp, **out)
+            os.replace(tmp, "logs/%s/histograms_%08d.npz" % (self.model_name, training_step))
+        return losses
 
     def _checkpoint_filename(self, episode):
         return 'checkpoints/%s_%08d' % (self.model_name, episode)

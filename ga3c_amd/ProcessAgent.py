@@ -37,7 +37,7 @@ def config_snapshot():
 
 
 class ProcessAgent(MP.Process):
-    def __init__(self, id, transport_name, episode_log_q, config=None):
+    def __init__(self, id, transport_name, episode_log_q, config=None, planes_pushed=0):
         super(ProcessAgent, self).__init__()
         self.id = id
         self.transport_name = transport_name
@@ -48,7 +48,9 @@ class ProcessAgent(MP.Process):
         self.time_count = 0
         self.transport = None
         self.env = None
-        self.planes_pushed = 0          # device front-end: frames handed over so far = sequence number of the next plane
+        # device front-end: frames handed over under this id so far = sequence number of the next plane (not 0 when the
+        # id was another agent's before: the device keeps counting, Server.add_agent)
+        self.planes_pushed = int(planes_pushed)
 
     # ---- pieces with the reference's names and semantics ------------------------------------
     @staticmethod

@@ -29,8 +29,7 @@ class Server:
         self.dp = engine_group
         self.dp_lock = threading.Lock()
         self.batch_lock = threading.Lock()      # one trainer at a time fills a batch (ThreadTrainer.py)
-        self.dp_started = False
-        self.stop_step = None
+        self.closing = False
         self.stats = ProcessStats()
         self.state_dim = self.get_state_dim()
         self.num_actions = self.get_num_action()
@@ -56,7 +55,7 @@ class Server:
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
                                                              self.state_dim)
         if self.dp is not None and hasattr(self.model, "comm_init"):
-            DataParallel.attach(self.model, self.dp.rank, self.dp.world)
+            DataParallel.attach(self.model, self.dp.rank, self.dp.world, rendezvous=self.dp.rv)
         # let the GPU read states straight out of the transport's slots (no host gather, no staging copy)
         self.zero_copy = bool(Config.ZERO_COPY) and hasattr(self.model, "register_transport")
         if self.zero_copy:
@@ -65,7 +64,10 @@ class Server:
             if not (self.zero_copy and hasattr(self.model, "frames_config")):
                 raise RuntimeError("FRONTEND = 'device' needs ZERO_COPY and a model with the frames_* entry points")
             # an agent can be ahead of the trainers by every rollout in flight plus the one it is filling
-            history = Config.FRAME_HISTORY or (self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8
+            # ... and a trainer gives a rollout's slot back when it has copied the row names, BEFORE the batch is trained:
+            # every trainer can hold TRAINING_MIN_BATCH_SIZE + TIME_MAX + 1 such rows, in the worst case of one agent
+            history = Config.FRAME_HISTORY or ((self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8 +
+                                               max(Config.TRAINERS, 2) * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1))
             self.model.frames_config(self.max_agents, Config.FRAME_HEIGHT, Config.FRAME_WIDTH, 3, history)
         if Config.LOAD_CHECKPOINT:
             try:
@@ -76,7 +78,9 @@ class Server:
         self.frame_counter = 0
         self._served_by_retired = 0
         self.agents = []
-        self.agent_id = 0
+        self.agent_id = 0                        # next never-used id
+        self.free_agent_ids = []                 # ids of removed agents, reusable once their last request is answered
+        self.failure = None                      # (worker name, exception) of the first batching thread that died
         self.predictors = []
         self.trainers = []
         self.dynamic_adjustment = ThreadDynamicAdjustment(self)
@@ -84,18 +88,33 @@ class Server:
 
     # ---- worker lifecycle (Server.py:106-139) ---------------------------------------------------
     def add_agent(self):
-        if self.agent_id >= self.max_agents:
-            return
-        self.agents.append(ProcessAgent(self.agent_id, self.transport.name, self.stats.episode_log_q, config_snapshot()))
+        """Server.py:106-110.  Agent ids index the transport's slots, so the ids of removed agents are reused (oldest
+        first) once their last request has been answered; a new id is taken only while there are slots left.  With the
+        random walk of ThreadDynamicAdjustment adding and removing agents for hours, ids would otherwise run out."""
+        agent_id = None
+        for k, cand in enumerate(self.free_agent_ids):
+            if self.transport.agent_idle(cand):
+                agent_id = self.free_agent_ids.pop(k)
+                break
+        if agent_id is None:
+            if self.agent_id >= self.max_agents:
+                return False
+            agent_id = self.agent_id
+            self.agent_id += 1
+        planes = self.model.frames_pushed(agent_id) if (self.device_frontend and hasattr(self.model, "frames_pushed")) else 0
+        self.agents.append(ProcessAgent(agent_id, self.transport.name, self.stats.episode_log_q, config_snapshot(), planes))
         self.agents[-1].start()
-        self.agent_id += 1
+        return True
 
     def remove_agent(self):
-        self.agents[-1].exit_flag.value = True
-        self.agents[-1].join(5)
-        if self.agents[-1].is_alive():
-            self.agents[-1].terminate()
+        agent = self.agents[-1]
+        agent.exit_flag.value = True
+        agent.join(5)
+        if agent.is_alive():
+            agent.terminate()
+            agent.join(5)
         self.agents.pop()
+        self.free_agent_ids.append(agent.id)
 
     def add_predictor(self):
         self.predictors.append(ThreadPredictor(self, len(self.predictors), self.state_dim, self.transport))
@@ -120,12 +139,17 @@ class Server:
         self.trainers.pop()
 
     # ---- training bookkeeping (Server.py:141-153) ----------------------------------------------
-    def _may_step(self):
-        """Data-parallel runs start after the first poll (shared lr / beta) and stop on an agreed global step
-        (EngineGroup); single-GPU runs never refuse."""
-        if self.dp is not None and not self.dp_started:
-            return False
-        return self.stop_step is None or self.training_step < self.stop_step
+    def _dp_gate(self):
+        """Data-parallel runs (call with dp_lock held): wait until rank 0's credit covers the next step, then set the
+        learning rate and beta that rank 0 attached to that step.  False = the group is stopping and this rank has
+        taken its last step (the batch is dropped, as the reference drops what is queued at exit)."""
+        dp = self.dp
+        while not dp.may_step(self.training_step):
+            if dp.finished(self.training_step) or self.closing or self.failure is not None:
+                return False
+            time.sleep(0.0005)
+        self.model.learning_rate, self.model.beta = dp.rates_for(self.training_step + 1)
+        return True
 
     def train_model(self, x_, r_, a_, x2, done, trainer_id):
         if self.dp is None:             # trainer threads go straight to the model, as in Server.py:141-142
@@ -133,42 +157,46 @@ class Server:
             self._count_train_step(x_.shape[0], x_, r_, a_)
             return
         with self.dp_lock:
-            if not self._may_step():
-                return
-            self.model.train(x_, r_, a_, x2, done, trainer_id)
-            self._count_train_step(x_.shape[0], x_, r_, a_)
+            if self._dp_gate():
+                self.model.train(x_, r_, a_, x2, done, trainer_id)
+                self._count_train_step(x_.shape[0], x_, r_, a_)
 
-    def _count_train_step(self, rows, x_, r_, a_):
+    def _count_train_step(self, rows, x_, r_, a_, **where):
         self.training_step += 1
         self.frame_counter += rows
         self.stats.training_count.value += 1
         self.dynamic_adjustment.temporal_training_count += 1
         if Config.TENSORBOARD and self.stats.training_count.value % Config.TENSORBOARD_UPDATE_FREQUENCY == 0:
-            self.model.log(x_, r_, a_, self.training_step)
+            self.model.log(x_, r_, a_, self.training_step, **where)     # the batch just trained (Server.py:149-150)
+
+    def worker_failed(self, worker, exc):
+        """A predictor / trainer thread died (a HIP error, a row that left the plane history, ...).  The reference lets
+        such a thread die silently and keeps running without it (Errors); here the first failure
+        is kept, main() stops the server and re-raises it, so the process ends with a non-zero status."""
+        if self.failure is None:
+            self.failure = (worker, exc)
 
     def train_model_rows(self, row_offsets, r_, a_, trainer_id):
         """train_model for rows that are still sitting in the transport (zero-copy intake)."""
         if self.dp is None:
             self.model.train_offsets(row_offsets, r_, a_)
-            self._count_train_step(row_offsets.shape[0], None, r_, a_)
+            self._count_train_step(row_offsets.shape[0], None, r_, a_, offsets=row_offsets)
             return
         with self.dp_lock:
-            if not self._may_step():
-                return
-            self.model.train_offsets(row_offsets, r_, a_)
-            self._count_train_step(row_offsets.shape[0], None, r_, a_)
+            if self._dp_gate():
+                self.model.train_offsets(row_offsets, r_, a_)
+                self._count_train_step(row_offsets.shape[0], None, r_, a_, offsets=row_offsets)
 
     def train_model_frames(self, agents, seqs, r_, a_, trainer_id):
         """train_model for rows whose states live in the device-side plane history (FRONTEND = 'device')."""
         if self.dp is None:
             self.model.train_frames(agents, seqs, r_, a_)
-            self._count_train_step(agents.shape[0], None, r_, a_)
+            self._count_train_step(agents.shape[0], None, r_, a_, frames=(agents, seqs))
             return
         with self.dp_lock:
-            if not self._may_step():
-                return
-            self.model.train_frames(agents, seqs, r_, a_)
-            self._count_train_step(agents.shape[0], None, r_, a_)
+            if self._dp_gate():
+                self.model.train_frames(agents, seqs, r_, a_)
+                self._count_train_step(agents.shape[0], None, r_, a_, frames=(agents, seqs))
 
     def save_model(self):
         self.model.save(self.stats.episode_count.value)
@@ -188,22 +216,27 @@ class Server:
                 if Config.SAVE_MODELS and self.stats.should_save_model.value > 0:
                     self.save_model()
                     self.stats.should_save_model.value = 0
+                if self.failure is not None:
+                    break
                 timed_out = max_seconds is not None and time.time() - t0 > max_seconds
-                if self.dp is not None:   # all ranks leave on the step rank 0 announces, and use rank 0's lr / beta
+                if self.dp is not None:
+                    # rank 0 decides when to stop and which lr / beta each step uses; every rank leaves on the same step
                     want_stop = timed_out or self.stats.episode_count.value >= Config.EPISODES
-                    self.stop_step, lr, beta = self.dp.poll(want_stop, self.training_step, lr, beta)
-                self.model.learning_rate, self.model.beta = lr, beta
-                self.dp_started = True
-                if self.dp is None:
+                    self.dp.poll(want_stop, self.training_step, lr, beta)
+                    if self.dp.finished(self.training_step):
+                        break
+                else:
+                    self.model.learning_rate, self.model.beta = lr, beta
                     if timed_out:
                         break
-                elif self.stop_step is not None and self.training_step >= self.stop_step:
-                    break
                 time.sleep(0.01)
         finally:
             self.shutdown()
+        if self.failure is not None:
+            raise RuntimeError("%s died: %r" % self.failure) from self.failure[1]
 
     def shutdown(self):
+        self.closing = True
         self.dynamic_adjustment.exit_flag = True
         if self.dynamic_adjustment.is_alive():      # it may still be starting workers (a run that ends at once)
             self.dynamic_adjustment.join(timeout=30)

@@ -48,6 +48,9 @@ class ThreadDynamicAdjustment(Thread):
         self._resize(len(s.trainers), self.trainer_count, s.add_trainer, s.remove_trainer)
         self._resize(len(s.predictors), self.predictor_count, s.add_predictor, s.remove_predictor)
         self._resize(len(s.agents), self.agent_count, s.add_agent, s.remove_agent)
+        # an add can be refused (no agent slot left): the walk, the accept / revert decision and the status line go on from
+        # what is really running, not from a move that did not happen
+        self.trainer_count, self.predictor_count, self.agent_count = len(s.trainers), len(s.predictors), len(s.agents)
 
     def random_walk(self):
         # one of {-1, 0, +1} for each of trainers, predictors, agents; never below 1

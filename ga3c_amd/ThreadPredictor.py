@@ -92,6 +92,16 @@ class ThreadPredictor(Thread):
             self.served += int(want.size)
 
     def run(self):
+        """The loop of the reference's run(); a failure is reported to the server instead of dying with the thread."""
+        try:
+            self._run()
+        except BaseException as e:   # noqa: BLE001
+            report = getattr(self.server, "worker_failed", None)
+            if report is None:
+                raise
+            report("%s %d" % (type(self).__name__, self.id), e)
+
+    def _run(self):
         t = self.transport
         if getattr(self.server, "device_frontend", False):
             return self._run_frames()

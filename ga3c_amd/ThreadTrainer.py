@@ -30,6 +30,16 @@ class ThreadTrainer(Thread):
         self.spills = 0                 # batches finished through the host path because the agents ran out of slots
 
     def run(self):
+        """The loop of the reference's run(); a failure is reported to the server instead of dying with the thread."""
+        try:
+            self._run()
+        except BaseException as e:   # noqa: BLE001
+            report = getattr(self.server, "worker_failed", None)
+            if report is None:
+                raise
+            report("%s %d" % (type(self).__name__, self.id), e)
+
+    def _run(self):
         t = self.transport
         cap = Config.TRAINING_MIN_BATCH_SIZE + t.train_rows
         state_dim = tuple(self.server.state_dim)

@@ -83,6 +83,10 @@ class Transport:
         rc = nat.check_host(self._lib.ga3c_pq_wait(self._h, agent, nat.ptr(p), C.byref(v), timeout_ms), "ga3c_pq_wait")
         return rc, p, v.value
 
+    def agent_idle(self, agent):
+        """True when every request of `agent` has been answered (its id may then be handed to a new agent)."""
+        return nat.check_host(self._lib.ga3c_pq_agent_idle(self._h, int(agent)), "ga3c_pq_agent_idle") == 1
+
     # ---- predictor side
     def pop_batch(self, ids, timeout_ms):
         return nat.check_host(self._lib.ga3c_pq_pop_batch(self._h, nat.ptr(ids, nat.u32p), ids.size, timeout_ms),

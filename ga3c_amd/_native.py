@@ -56,6 +56,9 @@ HIP_SIGNATURES = {
     "ga3c_net_predict_u8": (C.c_int, [C.c_void_p, u8p, C.c_int32, f32p, f32p, f32p]),
     "ga3c_net_train": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_train_u8": (C.c_int, [C.c_void_p, u8p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
+    "ga3c_net_evaluate": (C.c_int, [C.c_void_p, f32p, u8p, i64p, C.c_int32, f32p, f32p, C.c_int32, C.c_float, f32p, f32p, f32p,
+                                    f32p]),
+    "ga3c_net_evaluate_frames": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, f32p, f32p, f32p, f32p]),
     "ga3c_net_compute_grads": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32, C.c_float, f32p]),
     "ga3c_net_apply_grads": (C.c_int, [C.c_void_p, C.c_float]),
     "ga3c_net_register_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -71,6 +74,7 @@ HIP_SIGNATURES = {
     "ga3c_net_train_frames": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_frames_state": (C.c_int, [C.c_void_p, C.c_int32, u8p, i32p]),
     "ga3c_net_predict_frames": (C.c_int, [C.c_void_p, i32p, C.c_int32, f32p, f32p, f32p]),
+    "ga3c_net_frames_pushed": (C.c_int, [C.c_void_p, C.c_int32, i64p]),
     "ga3c_net_frames_upload": (C.c_int, [C.c_void_p, u8p, C.c_int32]),
     "ga3c_net_time_frames": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p]),
     "ga3c_net_upload": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int32]),
@@ -110,6 +114,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_submit_flags": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint32]),
     "ga3c_pq_request_flags": (C.c_int, [C.c_void_p, u32p, C.c_int32, u32p]),
     "ga3c_pq_wait": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32]),
+    "ga3c_pq_agent_idle": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),
     "ga3c_frame_preprocess": (C.c_int, [u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, u8p]),

@@ -516,6 +516,30 @@ int read_losses(ga3c_net* net, TrainLane& t, float* losses) {
   return GA3C_OK;
 }
 
+// Network.log (NetworkVP.py:259-265): forward + loss of the batch staged in train lane `t` on the newest weights, no
+// backward pass, no update.  losses = {cost_p_1_agg, cost_p_2_agg, cost_v}; d1 / v / p (each may be null) receive the
+// activations the reference histograms (NetworkVP_discrate.py:143-146).
+int evaluate_staged(ga3c_net* net, TrainLane& t, int B, float beta, float* losses, float* d1, float* v, float* p) {
+  int idx;
+  {
+    std::shared_lock<std::shared_mutex> lk(net->wmu);
+    idx = net->latest;
+  }
+  CHK(launch_forward(net, t.f, idx, B, t.st, true, &t, beta));
+  HeadBwdArgs hb;
+  memset(&hb, 0, sizeof hb);
+  hb.B = B; hb.A = net->A; hb.lossrow = t.lossrow; hb.losses = t.losses;
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, t.st, hb);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t.h_out, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
+  HIPCHK(hipStreamSynchronize(t.st));
+  if (losses) memcpy(losses, t.h_out, 3 * sizeof(float));
+  if (d1) HIPCHK(hipMemcpy(d1, t.f.d1, (size_t)B * HID * sizeof(float), hipMemcpyDeviceToHost));
+  if (v) HIPCHK(hipMemcpy(v, t.f.v, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
+  if (p) HIPCHK(hipMemcpy(p, t.f.p, (size_t)B * net->A * sizeof(float), hipMemcpyDeviceToHost));
+  return GA3C_OK;
+}
+
 // rows of a batch gathered from the registered host segment into x (device), on stream st
 // per-row byte offsets into the registered host segment, validated and copied into the lane's pinned array
 int stage_offsets(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off) {
@@ -994,6 +1018,25 @@ int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const f
   return read_losses(net, *t, losses);
 }
 
+int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const int64_t* offsets, int32_t offsets_u8,
+                      const float* y_r, const float* a, int32_t batch, float beta, float* losses, float* d1, float* v,
+                      float* p) {
+  if (!net || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  if ((x != nullptr) + (x_u8 != nullptr) + (offsets != nullptr) != 1)
+    return fail(GA3C_EINVAL, "evaluate: exactly one of x, x_u8, offsets names the states");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  TrainLane* tp = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
+  TrainLane& t = *tp;
+  if (offsets) {
+    CHK(launch_gather(net, offsets, batch, offsets_u8 != 0, t.h_off, t.f, t.st));
+    CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
+  } else {
+    CHK(stage_train_inputs(net, t, x ? (const void*)x : (const void*)x_u8, x == nullptr, y_r, a, batch));
+  }
+  return evaluate_staged(net, t, batch, beta, losses, d1, v, p);
+}
+
 int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes) {
   if (!net || !base || bytes < 16) return fail(GA3C_EINVAL, "bad argument");
   if (net->reg_host) return fail(GA3C_ESTATE, "a host segment is already registered");
@@ -1268,13 +1311,50 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   return GA3C_OK;
 }
 
+// rows named by (agent, plane sequence number) re-assembled from the plane history into train lane `t` (its mutex held)
+static int stage_history_rows(ga3c_net* net, TrainLane& t, const int32_t* agents, const int64_t* seqs, const float* y_r,
+                              const float* a, int32_t batch);
+
 int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses) {
   if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
-  Frames& f = net->fr;
-  if (!f.on || !f.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
-  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
+  if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
+  TrainLane* tp = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
+  TrainLane& t = *tp;
+  CHK(stage_history_rows(net, t, agents, seqs, y_r, a, batch));
+  CHK(train_grads(net, t, batch, beta));
+  CHK(train_apply(net, t, learning_rate));
+  return read_losses(net, t, losses);
+}
+
+int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                             int32_t batch, float beta, float* losses, float* d1, float* v, float* p) {
+  if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
+  TrainLane* tp = take_train_lane(net);
+  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
+  CHK(stage_history_rows(net, *tp, agents, seqs, y_r, a, batch));
+  return evaluate_staged(net, *tp, batch, beta, losses, d1, v, p);
+}
+
+int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed) {
+  if (!net || !pushed) return fail(GA3C_EINVAL, "null argument");
+  Frames& f = net->fr;
+  if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
+  if (agent < 0 || agent >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", agent, f.maxA);
+  std::lock_guard<std::mutex> g(f.mu);
+  *pushed = f.pushed[agent];
+  return GA3C_OK;
+}
+
+static int stage_history_rows(ga3c_net* net, TrainLane& t, const int32_t* agents, const int64_t* seqs, const float* y_r,
+                              const float* a, int32_t batch) {
+  Frames& f = net->fr;
   {
     std::lock_guard<std::mutex> g(f.mu);
     for (int i = 0; i < batch; ++i) {
@@ -1286,9 +1366,6 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
         return fail(GA3C_ESTATE, "row %d: plane %lld of agent %d has left the %d-plane history", i, (long long)(seqs[i] - (CIN - 1)), agents[i], f.hist);
     }
   }
-  TrainLane* tp = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
-  TrainLane& t = *tp;
   // the row descriptors ride in the lane's pinned offset array: seqs first, agent ids behind them
   int64_t* h_seq = t.h_off;
   int32_t* h_ag = reinterpret_cast<int32_t*>(t.h_in);
@@ -1299,10 +1376,7 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
   hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, t.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, t.f.xu8, batch);
   HIPCHK(hipGetLastError());
   t.f.x_u8 = true;   // (y_r and a are staged behind the x region of h_in: the ids at its start stay untouched)
-  CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta));
-  CHK(train_apply(net, t, learning_rate));
-  return read_losses(net, t, losses);
+  return stage_train_inputs(net, t, nullptr, false, y_r, a, batch);
 }
 
 int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n) {

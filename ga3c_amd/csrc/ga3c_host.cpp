@@ -723,6 +723,12 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
   return GA3C_H_OK;
 }
 
+int ga3c_pq_agent_idle(ga3c_shm* shm, int32_t agent) {
+  if (!shm || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad agent id");
+  AgentMeta* m = shm->meta(agent);
+  return m->req_seq == m->resp_seq.load(std::memory_order_acquire) ? 1 : 0;
+}
+
 int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t timeout_ms) {
   if (!shm || !ids || max_ids < 1) return fail(GA3C_H_EINVAL, "bad argument");
   Header* h = shm->hdr();

@@ -682,6 +682,9 @@ __device__ __forceinline__ void heads_bwd_role(const HeadBwdArgs& h, int role) {
   }
 }
 
+// loss sums alone (Network.log evaluates a batch without a backward pass: NetworkVP.py:259-265)
+__global__ __launch_bounds__(256) void loss_sum_kernel(HeadBwdArgs hb) { heads_bwd_role(hb, hb.A + 1); }
+
 // ------------------------------------------------------------------ dense1 backward: dWd = flat^T dd1
 // M = 3872 (kidx), N = 256, contraction over the batch.  Wave tile 32 x 32 (2 x 2 MFMA tiles).
 // grid.x = 121 row blocks, grid.y = 2, wave -> 32-column group (grid.y*4 + wave).

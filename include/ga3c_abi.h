@@ -90,6 +90,14 @@ int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float*
 /* Same, states as uint8 frames (converted on the GPU exactly like ga3c_net_predict_u8). */
 int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch,
                       float learning_rate, float beta, float* losses);
+/* log (NetworkVP.py:259-265 = sess.run(summary_op) on the batch it is given): forward + loss of `batch` rows on the
+ * current weights, no backward pass, no update, global_step unchanged.  The states come from exactly one of x (f32 host
+ * buffer), x_u8 (uint8 frames) or offsets (rows in the registered segment, offsets_u8 as in ga3c_net_train_gather).
+ * losses[3] = {cost_p_1_agg, cost_p_2_agg, cost_v}; d1 f32[B,256], v f32[B], p f32[B,A] (each may be NULL) receive the
+ * activations the reference histograms (NetworkVP_discrate.py:143-146: denselayer, logits_v, softmax_p). */
+int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const int64_t* offsets, int32_t offsets_u8,
+                      const float* y_r, const float* a, int32_t batch, float beta, float* losses, float* d1, float* v,
+                      float* p);
 /* The two halves of train, for tests and for callers that own the exchange step:
  * gradients only (left in arena 3), then the optimizer step on arena 3. */
 int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, const float* a,
@@ -168,6 +176,13 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
                           float* p, float* v);
 int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses);
+/* ga3c_net_evaluate for rows named by (agent, plane sequence number), as ga3c_net_train_frames takes them. */
+int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                             int32_t batch, float beta, float* losses, float* d1, float* v, float* p);
+/* Planes pushed into `agent`'s queue so far = sequence number its next plane gets.  Server.add_agent hands it to an
+ * agent process that takes over the id of a removed one, so that its rollouts keep naming planes the way the device
+ * counts them. */
+int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed);
 int ga3c_net_frames_state(ga3c_net* net, int32_t agent, uint8_t* state, int32_t* filled);
 int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, float* p, float* v, float* z);
 /* bench helpers: n frames resident in HBM, then `iters` pushes of them timed with events on the frames stream */

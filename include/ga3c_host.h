@@ -95,6 +95,10 @@ int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
 int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags);
 int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags);   /* predictor side */
 int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
+/* 1 when agent has no request in flight (every submit has been answered), 0 otherwise.  Server.add_agent (Server.py:106-110)
+ * reuses the id of a removed agent only once this holds: an agent that was stopped while waiting may have left a request
+ * behind, and a second submit on the same slot is refused while it is unanswered. */
+int ga3c_pq_agent_idle(ga3c_shm* shm, int32_t agent);
 /* predictor side (ThreadPredictor.py:50-55,61-63): block up to timeout for ONE request, then drain
  * without waiting up to max_ids; returns the count (0 on timeout). */
 int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t timeout_ms);

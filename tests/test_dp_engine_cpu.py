@@ -34,7 +34,7 @@ class _CollectiveStandIn:
         pass
 
 
-def _rank_main(rank, world, port, tmp, out_q):
+def _rank_main(rank, world, port, tmp, out_q, slow_poll=0.0):
     sys.path.insert(0, ROOT)
     os.chdir(tmp)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
@@ -49,18 +49,30 @@ def _rank_main(rank, world, port, tmp, out_q):
     Config.PRINT_STATS_FREQUENCY = 10 ** 9
     Config.RESULTS_FILENAME = "results_rank%d.txt" % rank
     Config.LEARNING_RATE_START = Config.LEARNING_RATE_END = 1e-3 * (rank + 1)   # deliberately different: rank 0's must win
-    group = DataParallel.EngineGroup.from_env()
+    os.environ["GA3C_DP_DIR"] = tmp
+    group = DataParallel.EngineGroup.from_env()           # the product's control plane: file + TCP rendezvous, no torch
+    if slow_poll and rank == 1:                           # this rank's main loop hears of every credit late
+        real_poll = group.poll
+
+        def late_poll(*a):
+            import time
+            time.sleep(slow_poll)
+            return real_poll(*a)
+        group.poll = late_poll
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # test-side stand-in for the RCCL data path only
     data_group = dist.new_group(backend="gloo")
     from Server import Server
     model = _CollectiveStandIn(6, data_group)
     srv = Server(model=model, max_agents=4, engine_group=group)
     srv.main(max_seconds=2.0 + rank)                      # ranks want to stop at different times
-    out_q.put((rank, srv.training_step, model.steps, sorted(set(model.lrs[-5:]))))
+    out_q.put((rank, srv.training_step, model.steps, sorted(set(model.lrs))))
+    group.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_servers_stop_on_the_same_train_step(tmp_path):
+@pytest.mark.parametrize("slow_poll", [0.0, 0.25])
+def test_two_servers_stop_on_the_same_train_step(tmp_path, slow_poll):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     s = socket.socket()
@@ -68,7 +80,7 @@ def test_two_servers_stop_on_the_same_train_step(tmp_path):
     port = s.getsockname()[1]
     s.close()
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q, slow_poll)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=500) for _ in procs)
@@ -77,4 +89,68 @@ def test_two_servers_stop_on_the_same_train_step(tmp_path):
         assert p.exitcode == 0
     (r0, steps0, m0, lr0), (r1, steps1, m1, lr1) = res
     assert steps0 == steps1 == m0 == m1 and steps0 > 10
-    assert lr0 == lr1 == [1e-3]                           # rank 0's learning rate reached rank 1
+    assert lr0 == lr1 == [1e-3]                           # EVERY step used rank 0's learning rate, on both ranks
+
+
+def test_credit_protocol_under_fast_steps_and_a_late_rank(tmp_path):
+    """The stop protocol at thousands of steps per second: two EngineGroups over real sockets, their
+    "train steps" return at once and meet in a barrier (the stand-in for the RCCL all-reduce: a step completes only
+    when both ranks take it), rank 1 polls late and irregularly.  No rank may enter a step the other never joins
+    (the barrier would time out), both end on the same step, every step used rank 0's learning rate of that step."""
+    import threading
+    import time
+    import ga3c_amd  # noqa: F401
+    import DataParallel as dp
+    world, port = 2, 45000 + os.getpid() % 10000
+    groups = [None, None]
+
+    def make(rank):
+        groups[rank] = dp.EngineGroup(rank, world, dp.Rendezvous(rank, world, tag="t", addr="127.0.0.1", port=port,
+                                                                  directory=str(tmp_path)))
+    ths = [threading.Thread(target=make, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30)
+    assert all(groups)
+    collective = threading.Barrier(world, timeout=20)
+    steps, used, errors = [0, 0], [[], []], []
+    done = [False, False]
+
+    def trainer(rank):
+        g = groups[rank]
+        try:
+            while True:
+                while not g.may_step(steps[rank]):
+                    if g.finished(steps[rank]):
+                        return
+                    time.sleep(0.0002)
+                lr, _ = g.rates_for(steps[rank] + 1)
+                collective.wait()                       # ncclAllReduce: needs every rank
+                used[rank].append(lr)
+                steps[rank] += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    def main_loop(rank):
+        g = groups[rank]
+        rng = np.random.default_rng(rank)
+        t0 = time.time()
+        while not g.finished(steps[rank]):
+            if rank == 1:
+                time.sleep(float(rng.uniform(0.0, 0.12)))      # up to a dozen poll periods late
+            lr = 1e-3 * (1 + steps[0] // 500)                   # rank 0's schedule moves while steps are in flight
+            g.poll(time.time() - t0 > 1.5, steps[rank], lr if rank == 0 else 99.0, 0.01)
+            time.sleep(0.01)
+        done[rank] = True
+
+    workers = [threading.Thread(target=f, args=(r,)) for r in range(world) for f in (trainer, main_loop)]
+    for t in workers:
+        t.start()
+    for t in workers:
+        t.join(60)
+    for g in groups:
+        g.close()
+    assert not errors, errors
+    assert all(done) and steps[0] == steps[1] > 1000, steps
+    assert used[0] == used[1] and 99.0 not in used[0] and len(set(used[0])) > 1

@@ -156,7 +156,8 @@ def test_device_front_end_protocol_on_cpu(tmp_path, monkeypatch):
         model = _DeviceFrontEndStandIn(6)
         srv = Server(model=model, max_agents=8)
         assert srv.device_frontend and srv.transport.row_bytes == 16 and srv.transport.state_bytes >= 210 * 160 * 3
-        assert model.history == (Config.MAX_QUEUE_SIZE + 2) * 6 + 8
+        # every rollout in flight + the one being filled, plus the rows the trainers stage after giving the slots back
+        assert model.history == (Config.MAX_QUEUE_SIZE + 2) * 6 + 8 + 2 * (11 + 6)
         srv.main(max_seconds=6)
         assert model.problems == []
         assert srv.predictions_served > 50 and sum(model.pred_sizes) == srv.predictions_served
@@ -253,3 +254,66 @@ def test_a_run_that_ends_at_once_shuts_down_cleanly(tmp_path, monkeypatch):
     srv = Server(model=_StandInModel(6), max_agents=8)
     srv.main()
     assert not srv.agents and not srv.predictors and not srv.trainers
+
+
+@pytest.mark.timeout(180)
+def test_agent_ids_are_recycled_and_counts_stay_real(tmp_path, monkeypatch):
+    """with DYNAMIC_SETTINGS every +1 of the random walk used to consume an agent id for good.  Here: far
+    more add / remove cycles than there are slots; every add must start a live agent, ids stay inside the transport,
+    and the dynamic adjustment's targets follow what is really running when an add is refused."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=2, PREDICTORS=1, TRAINERS=1, SYNTHETIC_EPISODE_LENGTH=15, TIME_MAX=5, DYNAMIC_SETTINGS=False,
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=0, NUM_ACTIONS=6, PRINT_STATS_FREQUENCY=10 ** 9).items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    import threading
+    model = _StandInModel(6)
+    srv = Server(model=model, max_agents=3)
+    th = threading.Thread(target=srv.main, kwargs=dict(max_seconds=8), daemon=True)
+    th.start()
+    import time
+    t0 = time.time()
+    while len(srv.agents) < 2 and time.time() - t0 < 20:
+        time.sleep(0.05)
+    seen = set()
+    for cycle in range(7):                                   # 7 removals + 7 adds on 3 slots
+        srv.remove_agent()
+        assert srv.add_agent() is True
+        seen.add(srv.agents[-1].id)
+        assert len(srv.agents) == 2 and all(a.is_alive() for a in srv.agents)
+        assert len({a.id for a in srv.agents}) == 2 and all(0 <= a.id < 3 for a in srv.agents)
+    assert seen <= {0, 1, 2}
+    assert srv.add_agent() is True and srv.add_agent() is False           # third slot, then none left
+    da = srv.dynamic_adjustment
+    da.agent_count = 5                                       # the walk asks for more than fits
+    da.enable_disable_components()
+    assert da.agent_count == len(srv.agents) == 3
+    served = srv.predictions_served
+    time.sleep(0.5)
+    assert srv.predictions_served > served                   # the recycled agents are being served
+    th.join(60)
+    assert not th.is_alive() and srv.failure is None
+
+
+class _FailingModel(_StandInModel):
+    def train(self, x, y_r, a, x2, done, tid):
+        raise RuntimeError("device lost")
+
+
+@pytest.mark.timeout(120)
+def test_server_stops_and_raises_when_a_worker_thread_dies(tmp_path, monkeypatch):
+    """A trainer (or predictor) thread that dies used to leave the agents waiting forever; the server now stops and main()
+    re-raises, so `python GA3C.py` ends with a non-zero status."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=2, PREDICTORS=1, TRAINERS=1, SYNTHETIC_EPISODE_LENGTH=15, TIME_MAX=5, DYNAMIC_SETTINGS=False,
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=0, NUM_ACTIONS=6, PRINT_STATS_FREQUENCY=10 ** 9).items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    srv = Server(model=_FailingModel(6), max_agents=4)
+    with pytest.raises(RuntimeError, match="ThreadTrainer 0 died"):
+        srv.main(max_seconds=60)
+    assert not srv.agents and not srv.trainers and not srv.predictors
