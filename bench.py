@@ -40,14 +40,14 @@ HBM_PEAK_GBS = 8000.0                                                   # MI355X
 MFMA_F32_PEAK_TFLOPS = 157.3                                            # MI355X_MICROARCH.md, f32-input MFMA
 
 
-def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2):
+def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2, trainers=2, min_batch=None, engine_group=None):
     """The whole engine for `seconds`: synthetic agents -> shm transport -> ThreadPredictor / ThreadTrainer -> `model`
     (None = the HIP Network).  Returns rates over the steady window of the run."""
     import threading
     from Config import Config
     from Server import Server
-    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = agents, predictors, 2
-    Config.TRAINING_MIN_BATCH_SIZE = B - 1
+    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = agents, predictors, trainers
+    Config.TRAINING_MIN_BATCH_SIZE = B - 1 if min_batch is None else min_batch
     Config.DYNAMIC_SETTINGS, Config.SAVE_MODELS, Config.TENSORBOARD = False, False, False
     Config.PRINT_STATS_FREQUENCY = 10 ** 9
     Config.RESULTS_FILENAME = os.devnull
@@ -56,7 +56,7 @@ def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2):
     real_stdout = sys.stdout
     sys.stdout = sys.stderr
     try:
-        srv = Server(model=model, max_agents=agents)
+        srv = Server(model=model, max_agents=agents, engine_group=engine_group)
         marks, native = [], []
 
         def sampler():      # steady window: from 40% of the run (agents forked, queues warm) to just before the stop
@@ -81,7 +81,7 @@ def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2):
                       "train_rows_per_step": (fb - fa) / max(sb - sa, 1), "mean_predict_batch": (pb - pa) / max(bb - ba, 1)}
         else:
             steady = dict(whole, train_rows_per_step=srv.frame_counter / max(srv.training_step, 1), mean_predict_batch=None)
-        res = dict(steady, agents=agents, predictors=predictors, trainers=2, whole_run=whole,
+        res = dict(steady, agents=agents, predictors=predictors, trainers=trainers, whole_run=whole,
                    native_predictor_loop=bool(native and native[0]))
         if model is None:
             srv.model.close()
@@ -194,7 +194,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode, steps, lanes=0):
+    def timed_block(mode, steps, lanes=0):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks of the wall time."""
         ev_ms = nat.C.c_float()
         barrier_sync()
         t0 = time.perf_counter()
@@ -211,19 +212,48 @@ def main():
             return float(tmax[0]), ev_ms.value
         return t1 - t0, ev_ms.value
 
+    MIN_TIMED_S, MAX_BLOCKS = 0.05, 400
+    blocks_used = {}
+
+    def timed(mode, steps, lanes=0, tag=None):
+        """A K-step block of this path lasts well under a millisecond at the driver's K = 20, which is mostly the start-up
+        of the streams: the bracketed K-step block is repeated until at least 50 ms have been timed and the MEDIAN block
+        is reported (every rank runs the same number of blocks: the count is decided on rank 0's clock)."""
+        walls, evs, total = [], [], 0.0
+        while True:
+            w, e = timed_block(mode, steps, lanes)
+            walls.append(w)
+            evs.append(e)
+            total += w
+            more = 1 if (total < MIN_TIMED_S and len(walls) < MAX_BLOCKS) else 0
+            if world > 1:
+                flag = torch.tensor([more if rank == 0 else 0])
+                dist.broadcast(flag, src=0)
+                more = int(flag[0])
+            if not more:
+                break
+        if tag:
+            blocks_used[tag] = len(walls)
+        return float(np.median(walls)), float(np.median(evs))
+
     ev_ms = nat.C.c_float()
     for mode in (0, 1):
         if W > 0:
             nat.check(lib.ga3c_net_time_resident(h, mode, B, W, lr, beta, nat.C.byref(ev_ms)), "warmup")
     if W > 0:
         nat.check(lib.ga3c_net_time_predict_lanes(h, B, W, NP, nat.C.byref(ev_ms)), "warmup")
-    pred_s, _ = timed(0, K, lanes=NP)
+    pred_s, _ = timed(0, K, lanes=NP, tag="predict")
     one_s, pred_ev_ms = timed(0, K)
     three_s = pred_s if args.no_lane_sweep else timed(0, K, lanes=3)[0]
     if dp_error is None:
-        train_s, train_ev_ms = timed(1, K)
+        train_s, train_ev_ms = timed(1, K, tag="train")
     else:                                               # no communicator: the data-parallel train leg is not measured
         train_s, train_ev_ms = None, None
+    allreduce_us = None
+    if world > 1 and dp_error is None:      # the exchange step alone: 4.02 MB f32 sum all-reduce, events on the train stream
+        barrier_sync()
+        nat.check(lib.ga3c_net_time_allreduce(h, 50, nat.C.byref(ev_ms)), "time_allreduce")
+        allreduce_us = ev_ms.value / 50 * 1e3
     # the engine's own intake format: uint8 frames resident in HBM, converted inside the conv kernels (extra figure)
     xk = np.ascontiguousarray(((x + np.float32(1)) * np.float32(128)).astype(np.uint8))
     nat.check(lib.ga3c_net_upload_u8(h, nat.ptr(xk, nat.u8p), nat.ptr(y_r), nat.ptr(act), B), "upload_u8")
@@ -252,7 +282,15 @@ def main():
                       "workload": "forward+loss+backward%s+RMSProp, %d rows per GPU (BASELINE configs[2])"
                                   % ("+RCCL all-reduce(sum) of 4.02 MB grads" if world > 1 else "", B)},
             "stream_ms_per_step": {"predict": pred_ev_ms / K, "train": train_ev_ms / K if train_ev_ms else None},
+            "timed_blocks": dict(blocks_used, min_timed_ms=MIN_TIMED_S * 1e3,
+                                 note="the bracketed K-step block is repeated until >= 50 ms are timed; ms_per_step and "
+                                      "value are those of the MEDIAN block"),
             "data_parallel_error": dp_error,
+            "rccl_ranks": world if (world > 1 and dp_error is None) else (1 if world == 1 else 0),
+            "allreduce_us": allreduce_us,
+            "allreduce_note": "average of 50 back-to-back ncclAllReduce(sum, f32, 1,005,623 elements = 4.02 MB) on the train "
+                              "stream, HIP events around them; inside a train step the dense1/w part overlaps with the conv "
+                              "backward kernels" if world > 1 else None,
             "uint8_resident": {"predictions_per_sec": world * K * B / u8_s,
                                "training_steps_per_sec": K / u8_train_s if u8_train_s else None,
                                "note": "same legs with the batch resident as uint8 frames (28,224 B per state), the "
@@ -272,42 +310,64 @@ def main():
         flop_launch = (FLOP_CONV1_PER_SAMPLE + FLOP_CONV2_PER_SAMPLE) * B
         t_conv = kernels["conv_stack_fwd"] * 1e-6
         achieved = flop_launch / t_conv / 1e12
-        traffic = None
+        traffic, traffic_commit, traffic_src = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("conv_stack_fwd_B%d" % B)
+                tj = json.load(f)
+            traffic = tj.get("conv_stack_fwd_B%d" % B)
+            traffic_commit, traffic_src = tj.get("commit"), tj.get("source")
         out["roofline"] = {"kernel": "conv_stack_fwd_kernel<false>", "bound": "mfma", "achieved": achieved,
                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                           "traffic": traffic, "avg_launch_us": kernels["conv_stack_fwd"],
-                           "algorithmic_flop_per_launch": flop_launch}
+                           "traffic": traffic, "traffic_commit": traffic_commit, "traffic_source": traffic_src,
+                           "avg_launch_us": kernels["conv_stack_fwd"], "algorithmic_flop_per_launch": flop_launch,
+                           "algorithmic_bytes_per_launch": B * (84 * 84 * 4 * 4 + 11 * 11 * 32 * 4) + 4 * (4112 + 8224)}
         out["kernel_us"] = kernels
         flop = FLOP_PER_PREDICTION.get(A, 7_581_184)
         out["end_to_end_mfma_frac"] = out["value"] * flop / (world * MFMA_F32_PEAK_TFLOPS * 1e12)
 
-    # ---- CPU baseline: the oracle's C port on this box's host cores (rank 0, N = 1 only)
+    # ---- CPU baseline: the oracle's C port on this box's host cores, kernel-only, forward and
+    # forward-backward + RMSProp at B in {1, 32, 128, 512} (rank 0, N = 1 only).  The headline sample is the bench batch.
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         import ga3c_oracle_cport as oc
         oc.lib().ga3c_oc_set_threads(min(os.cpu_count() or 1, 16))   # a one-GPU box's CPU share is 16 cores
         theta = net.get_arena(0)
-        oc.predict(theta, A, x)
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < args.cpu_seconds:
-            oc.predict(theta, A, x)
-            n += 1
-        dt = time.perf_counter() - t0
-        ms = np.ones_like(theta)
-        th2 = theta.copy()
-        oc.train(th2, ms, A, x, y_r, act, lr, beta)
-        m, t1 = 0, time.perf_counter()
-        while time.perf_counter() - t1 < args.cpu_seconds:
-            oc.train(th2, ms, A, x, y_r, act, lr, beta)
-            m += 1
-        dt2 = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": n * B / dt, "unit": "predictions/s", "cores": oc.threads(), "kind": "port",
+        crng = np.random.Generator(np.random.PCG64(12345))            # Config.py:187
+
+        def cpu_leg(bsz, seconds):
+            xb = crng.integers(0, 256, size=(bsz, 84, 84, 4), dtype=np.uint8).astype(np.float32) / np.float32(128) - np.float32(1)
+            ab = np.eye(A, dtype=np.float32)[crng.integers(0, A, bsz)]
+            yb = crng.uniform(-1, 1, bsz).astype(np.float32)
+            if bsz == B:
+                xb, ab, yb = x, act, y_r
+            oc.predict(theta, A, xb)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                oc.predict(theta, A, xb)
+                n += 1
+            dt = time.perf_counter() - t0
+            ms, th2 = np.ones_like(theta), theta.copy()
+            oc.train(th2, ms, A, xb, yb, ab, lr, beta)
+            m, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < 0.6 * seconds:
+                oc.train(th2, ms, A, xb, yb, ab, lr, beta)
+                m += 1
+            dt2 = time.perf_counter() - t1
+            return {"predictions_per_sec": n * bsz / dt, "train_steps_per_sec": m / dt2, "forward_passes": n,
+                    "train_steps": m, "seconds": dt + dt2}
+
+        head = cpu_leg(B, 0.4 * args.cpu_seconds)
+        sizes = {str(B): head}
+        for bsz in (1, 32, 128, 512):
+            if bsz != B:
+                sizes[str(bsz)] = cpu_leg(bsz, 0.1 * args.cpu_seconds)
+        out["cpu_baseline"] = {"value": head["predictions_per_sec"], "unit": "predictions/s", "cores": oc.threads(), "kind": "port",
                                "sample": "%d forward passes of the same %d-state batch (%.1f s) by oracle/ga3c_oracle_c.c, "
-                                         "OpenMP over %d threads of %d host cores" % (n, B, dt, oc.threads(), os.cpu_count()),
-                               "train_steps_per_sec": m / dt2}
+                                         "OpenMP over %d threads of %d host cores"
+                                         % (head["forward_passes"], B, head["seconds"], oc.threads(), os.cpu_count()),
+                               "train_steps_per_sec": head["train_steps_per_sec"],
+                               "kernel_only_by_batch": dict(sizes, note="BASELINE.md section 4 item 1: forward and forward-backward + "
+                                                            "RMSProp at B in {1, 32, 128, 512}, same C port, same threads")}
 
     cpu_theta = net.get_arena(0) if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
     net.close()
@@ -395,12 +455,50 @@ def main():
         out["e2e"]["raw_frames"] = raw
         if cpu_theta is not None:      # the same harness with the oracle's C port as the model: the CPU path beside it
             import ga3c_oracle_cport as oc
+            # BASELINE.md section 4 item 2 = BASELINE.json configs[0]: 4 agents / 1 predictor / 1 trainer, the reference's default
+            # TRAINING_MIN_BATCH_SIZE = 0 (one rollout per train step, Config.py:118), CPU model; and the HIP engine beside it
+            oc.lib().ga3c_oc_set_threads(8)       # one predictor + one trainer thread call in concurrently: 2 x 8 = the 16-core share
+            short = max(3.0, 0.5 * args.e2e_seconds)
+            out["cpu_baseline"]["e2e_config0"] = dict(
+                run_engine(CPortModel(oc, cpu_theta, A), short, 4, B, A, predictors=1, trainers=1, min_batch=0),
+                note="BASELINE configs[0]: 4 agents / 1 predictor / 1 trainer, TRAINING_MIN_BATCH_SIZE = 0, model = "
+                     "oracle/ga3c_oracle_c.c (8 OpenMP threads per calling thread)")
+            out["e2e"]["config0"] = dict(
+                run_engine(None, short, 4, B, A, predictors=1, trainers=1, min_batch=0),
+                note="the same configs[0] shape on the HIP engine")
             oc.lib().ga3c_oc_set_threads(4)       # 2 predictor + 2 trainer threads call in concurrently: 4 x 4 = the 16-core share
             out["cpu_baseline"]["e2e"] = dict(
-                run_engine(CPortModel(oc, cpu_theta, A), args.e2e_seconds, args.e2e_agents, B, A),
-                note="same agents / transport / batcher threads, model = oracle/ga3c_oracle_c.c (host-buffer path, 4 OpenMP "
-                     "threads per calling thread)")
+                run_engine(CPortModel(oc, cpu_theta, A), short, args.e2e_agents, B, A),
+                note="extra: the 32-agent / 2 / 2 engine shape of the `e2e` leg with the C port as the model (host-buffer path, "
+                     "4 OpenMP threads per calling thread)")
 
+    # ---- N-rank engine: one Server per GPU (own agents, own transport), lock-step training over RCCL (DataParallel.EngineGroup)
+    if world > 1 and args.e2e_seconds > 0 and dp_error is None:
+        import threading
+
+        def give_up():      # a rank that never joins a collective would hang the job: the line is printed without this leg
+            if rank == 0:
+                out["e2e"] = {"error": "the %d-rank engine leg did not finish within its time limit" % world}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        guard = threading.Timer(args.e2e_seconds + 90.0, give_up)
+        guard.daemon = True
+        guard.start()
+        Config.DEVICE = "gpu:%d" % local_rank
+        Config.RANDOM_SEED += 100003 * rank
+        group = DataParallel.EngineGroup(rank, world)
+        res = run_engine(None, args.e2e_seconds, args.e2e_agents, B, A, engine_group=group)
+        group.close()
+        guard.cancel()
+        tot = torch.tensor([res["predictions_per_sec"], res["training_steps_per_sec"], res["whole_run"]["training_steps_per_sec"]],
+                           dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            out["e2e"] = {"predictions_per_sec": float(tot[0]), "training_steps_per_sec": float(tot[1]) / world,
+                          "agents": world * args.e2e_agents, "ranks": world, "rank0": res,
+                          "note": "one engine per GPU (%d agents, 2 predictors, 2 trainers each); predictions are summed over "
+                                  "the ranks, a train step is a GLOBAL step (every rank's %d-row shard + RCCL all-reduce)"
+                                  % (args.e2e_agents, B)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -72,6 +72,7 @@ class Config:
 
     # ---- engine knobs (no counterpart in the reference) ----------------------------------------
     NUM_ACTIONS = 6                     # synthetic source only (Pong 6, Breakout 4, Boxing 18)
+    MAX_SECONDS = 0                     # > 0: Server.main stops after this many seconds (the reference stops on EPISODES only)
     RETURN_MODE = 'fork'                # 'fork': ProcessAgent.py:69-84 bit-exact; 'nstep': upstream n-step
     STATE_TRANSPORT = 'u8'              # 'u8': ship uint8 frames, convert on GPU; 'f32': ship f32 states
     SYNTHETIC_EPISODE_LENGTH = 1000

@@ -34,7 +34,8 @@ if __name__ == '__main__':
         Config.SAVE_MODELS = Config.SAVE_MODELS and group.rank == 0
     from Server import Server
     try:
-        Server(engine_group=group).main()        # raises (non-zero exit status) if a predictor / trainer thread died
+        # raises (non-zero exit status) if a predictor / trainer thread died
+        Server(engine_group=group).main(max_seconds=Config.MAX_SECONDS or None)
     finally:
         if group is not None:
             group.close()

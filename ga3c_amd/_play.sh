@@ -1,1 +1,1 @@
-python GA3C.py PLAY_MODE=True "$@"
+python "$(dirname "$0")/GA3C.py" PLAY_MODE=True "$@"

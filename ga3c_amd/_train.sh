@@ -1,2 +1,2 @@
 mkdir -p checkpoints logs
-python GA3C.py "$@"
+python "$(dirname "$0")/GA3C.py" "$@"

@@ -1698,6 +1698,26 @@ int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int3
   return GA3C_OK;
 }
 
+int ga3c_net_time_allreduce(ga3c_net* net, int32_t iters, float* elapsed_ms) {
+  // `iters` back-to-back all-reduces (sum) of the gradient arena -- the exchange step of a data-parallel train step, alone
+  // on the train stream -- between two HIP events recorded on that stream.  Collective: every rank calls it.
+  if (!net || !elapsed_ms || iters < 1) return fail(GA3C_EINVAL, "bad argument");
+  if (!net->comm) return fail(GA3C_ESTATE, "no communicator attached");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  TrainLane& t = net->tr;
+  NCCLCHK(ncclAllReduce(net->grad, net->grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));   // warm
+  HIPCHK(hipEventRecord(t.ev0, t.st));
+  for (int i = 0; i < iters; ++i)
+    NCCLCHK(ncclAllReduce(net->grad, net->grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
+  HIPCHK(hipEventRecord(t.ev1, t.st));
+  HIPCHK(hipEventSynchronize(t.ev1));
+  HIPCHK(hipEventElapsedTime(elapsed_ms, t.ev0, t.ev1));
+  HIPCHK(hipMemsetAsync(net->grad, 0, (size_t)net->n * sizeof(float), t.st));   // the repeated sums may have overflowed
+  HIPCHK(hipStreamSynchronize(t.st));
+  return GA3C_OK;
+}
+
 int ga3c_net_allreduce_grads(ga3c_net* net) {
   if (!net) return fail(GA3C_EINVAL, "null argument");
   if (!net->comm) return fail(GA3C_ESTATE, "no communicator attached");

@@ -201,6 +201,9 @@ int ga3c_host_free(void* ptr);
 #define GA3C_COMM_ID_BYTES 128
 int ga3c_comm_make_id(uint8_t id[GA3C_COMM_ID_BYTES]);
 int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int32_t rank, int32_t world);
+/* `iters` back-to-back all-reduces of the gradient arena between two HIP events on the train stream (bench.py's
+ * allreduce_us).  Collective: every rank of the communicator calls it. */
+int ga3c_net_time_allreduce(ga3c_net* net, int32_t iters, float* elapsed_ms);
 int ga3c_net_allreduce_grads(ga3c_net* net);
 
 #ifdef __cplusplus

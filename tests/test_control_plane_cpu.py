@@ -159,3 +159,16 @@ def test_gym_frame_source_fails_loudly_without_gym(monkeypatch):
     monkeypatch.setattr(Config, "FRAME_SOURCE", "gym")
     with pytest.raises(ImportError, match="FRAME_SOURCE = 'gym'"):
         Environment(0)
+
+
+def test_mixed_launcher_builds_one_engine_per_game():
+    import ga3c_amd  # noqa: F401
+    import GA3C_mixed as gm
+    games = gm.parse_games("Boxing:18:0+1+2+3,Pong:6:4")
+    assert games == [("Boxing", 18, [0, 1, 2, 3]), ("Pong", 6, [4])]
+    (n0, c0, e0), (n1, c1, e1) = gm.commands(games, ["AGENTS=256"])
+    assert "torch.distributed.run" in c0 and "--nproc-per-node" in c0 and e0["HIP_VISIBLE_DEVICES"] == "0,1,2,3"
+    assert "NUM_ACTIONS=18" in c0 and "NETWORK_NAME=Boxing" in c0 and "AGENTS=256" in c0
+    assert "DEVICE=gpu:4" in c1 and "RESULTS_FILENAME=results_Pong.txt" in c1
+    with pytest.raises(ValueError):
+        gm.parse_games("Pong:6,Pong:6")

@@ -375,3 +375,51 @@ def test_graph_replayed_prediction_steps_are_bit_identical(nets, monkeypatch):
         g.close()
         plain.set_arena(0, _flat(o.init_params(6), 6))
         plain.set_arena(1, np.ones(plain.param_count, np.float32))
+
+
+def test_log_evaluates_the_batch_it_is_given_and_writes_histograms(nets, tmp_path, monkeypatch):
+    """Network.log (NetworkVP.py:259-265): forward + loss on ITS arguments with the current weights -- not the last train
+    step's numbers -- plus the histograms of NetworkVP_discrate.py:140-146, held to the oracle."""
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import histogram_proto
+    monkeypatch.chdir(tmp_path)
+    net = nets(6)
+    net.set_arena(0, _flat(o.init_params(6), 6))
+    net.set_arena(1, np.ones(net.param_count, np.float32))
+    xk, x, a, y = _batch(21, 6, 808)
+    xk2, x2, a2, y2 = _batch(33, 6, 809)
+    net.learning_rate, net.beta = 3e-4, 0.01
+    net.train(x, y, a)                                   # some OTHER batch was trained last
+    step = net.get_global_step()
+    theta = net.get_arena(0)
+    losses = net.log(xk2, y2, a2, 41)                    # uint8 input
+    losses_f32 = net.log(x2, y2, a2, 42)                 # the same rows as f32
+    assert np.array_equal(losses, losses_f32)
+    assert net.get_global_step() == step and np.array_equal(net.get_arena(0), theta)     # log trains nothing
+    params = _oracle_params(net)
+    ref_l, _ = o.loss_and_grads(params, x2.astype(np.float64), y2, a2.astype(np.float64), 0.01)
+    want = np.array([ref_l["cost_p_1_agg"], ref_l["cost_p_2_agg"], ref_l["cost_v"]])
+    assert np.allclose(losses, want, rtol=1e-4, atol=1e-4)
+    rows = [r.split(",") for r in open("logs/test/scalars.csv").read().strip().splitlines()]
+    assert [int(r[0]) for r in rows] == [41, 42] and all(len(r) == 7 for r in rows)
+    got = np.array([float(t) for t in rows[0][1:]])
+    assert np.allclose(got, [want[0], want[1], -(want[0] + want[1]), want[2], 3e-4, 0.01], rtol=1e-4, atol=1e-4)
+    ref = o.forward(params, x2.astype(np.float64), keep=True)
+    with np.load("logs/test/histograms_00000041.npz") as z:
+        tags = {k.rsplit("/", 1)[0] for k in z.files}
+        assert tags == {"weights_%s:0" % n for n in o.PARAM_ORDER} | {"activation_lastdense", "activation_v", "activation_p"}
+        for tag, values in (("activation_lastdense", ref["d1"]), ("activation_v", ref["v"]), ("activation_p", ref["p"]),
+                            ("weights_dense1/w:0", params["dense1/w"]), ("weights_logits_p/b:0", params["logits_p/b"])):
+            h = histogram_proto(values)
+            assert z[tag + "/num"] == h["num"] == np.asarray(values).size
+            assert abs(z[tag + "/min"] - h["min"]) < TOL and abs(z[tag + "/max"] - h["max"]) < TOL
+            assert abs(z[tag + "/sum"] - h["sum"]) < TOL * max(1.0, abs(h["sum"])) * 10
+            assert abs(z[tag + "/sum_squares"] - h["sum_squares"]) < TOL * max(1.0, h["sum_squares"]) * 10
+            assert z[tag + "/bucket"].sum() == h["num"] and np.all(np.diff(z[tag + "/bucket_limit"]) > 0)
+            # same buckets up to values that sit within f32 rounding of a bucket limit
+            lim = np.union1d(z[tag + "/bucket_limit"], h["bucket_limit"])
+            cg = np.zeros(lim.size)
+            cw = np.zeros(lim.size)
+            cg[np.searchsorted(lim, z[tag + "/bucket_limit"])] = z[tag + "/bucket"]
+            cw[np.searchsorted(lim, h["bucket_limit"])] = h["bucket"]
+            assert np.abs(cg - cw).sum() <= max(4, 0.002 * h["num"]), tag
