@@ -20,6 +20,7 @@
 #include <new>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1503,13 +1504,30 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
     std::shared_lock<std::shared_mutex> lk(net->wmu);
     idx = net->latest;   // == cur after the sync_all above
   }
+  // one host thread per lane, as the engine's NP predictor threads drive them (ThreadPredictor.py:45-66); lane l takes the
+  // steps l, l + nlanes, ... of the `iters`
+  std::vector<int> rcs((size_t)nlanes, GA3C_OK);
+  std::vector<std::string> errs((size_t)nlanes);
   const auto h0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < iters; ++i) {
-    Lane* L = net->lanes[i % nlanes];
-    CHK(lane_step(net, *L, idx, batch, STEP_RESIDENT, nullptr, nullptr));
+  auto drive = [&](int l) {
+    if (hipSetDevice(net->cfg.device) != hipSuccess) { rcs[l] = GA3C_EHIP; return; }
+    Lane* L = net->lanes[l];
+    for (int i = l; i < iters; i += nlanes) {
+      const int rc = lane_step(net, *L, idx, batch, STEP_RESIDENT, nullptr, nullptr);
+      if (rc != GA3C_OK) { rcs[l] = rc; errs[l] = g_err; return; }
+    }
+    if (hipStreamSynchronize(L->st) != hipSuccess) rcs[l] = GA3C_EHIP;
+  };
+  if (nlanes == 1) {
+    drive(0);
+  } else {
+    std::vector<std::thread> ths;
+    for (int l = 0; l < nlanes; ++l) ths.emplace_back(drive, l);
+    for (auto& t : ths) t.join();
   }
-  for (int l = 0; l < nlanes; ++l) HIPCHK(hipStreamSynchronize(net->lanes[l]->st));
   *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+  for (int l = 0; l < nlanes; ++l)
+    if (rcs[l] != GA3C_OK) return fail(rcs[l], "prediction lane %d failed: %s", l, errs[l].c_str());
   return GA3C_OK;
 }
 

@@ -37,6 +37,22 @@ constexpr int64_t OFF_W1 = 0, OFF_B1 = OFF_W1 + 256 * 16, OFF_W2 = OFF_B1 + 16, 
 __host__ __device__ inline int64_t off_bp(int A) { return OFF_WP + (int64_t)HID * A; }
 __host__ __device__ inline int64_t arena_floats(int A) { return off_bp(A) + A; }
 
+// In-kernel time stamps for the DIAGNOSTIC build of tools/kprobe.hip only (-DGA3C_STAMPS): the product library never
+// defines it, so no stamp executes there.  Stamps leave the kernel through a buffer of their own.
+#ifdef GA3C_STAMPS
+__device__ unsigned long long* ga3c_stamp_buf = nullptr;     // [workgroup][16 waves][16 stamps]
+__device__ __forceinline__ void stamp_(int k) {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if ((threadIdx.x & 63) == 0 && ga3c_stamp_buf) ga3c_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + k] = t;
+}
+#define GA3C_STAMP(k) stamp_(k)
+#else
+#define GA3C_STAMP(k)
+#endif
+
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -277,17 +293,33 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ conv1 + conv2 forward in one launch
-// Workgroup (16 waves) = (sample, upper / lower half of the conv2 output).  The x rows the half needs (48 or
-// 52 padded rows, <= 72 KB) and both filter banks go to LDS once; conv1 runs tile by tile and leaves its
-// ReLU output in an LDS image of n1 laid out for conv2 (zero border included), conv2 then reads its patches
-// from that image.  n1 never travels to HBM in prediction (TRAIN also stores it: the backward pass needs it).
-// Rows 9,10 of n1 are needed by both halves and are computed twice (+9.5% conv1 MFMAs, identical values).
+// Workgroup (16 waves) = (sample, half of the conv2 output).  The x rows the half needs (56 or 52 padded rows,
+// <= 77 KB) and both filter banks go to LDS once; conv1 runs tile by tile and leaves its ReLU output in an LDS image
+// of n1 laid out for conv2 (zero border included), conv2 then reads its patches from that image.  n1 never travels
+// to HBM in prediction (TRAIN also stores it: the backward pass needs it).
+// The 121 conv2 pixels are cut by PIXEL, 60 | 61, not by row: each half then has exactly 4 conv2 tiles (8 items of 64
+// MFMAs, two per SIMD) and at most 16 conv1 tiles (one per wave, four per SIMD) -- the row cut 55 | 66 left the lower
+// half with 5 tiles, i.e. three items on two of its SIMDs, and that half set the kernel's length.  The n1 pixels a half
+// needs are then ragged: upper = rows 0..10 whole + rows 11,12 columns 0..10 (253 px); lower = rows 9,10 columns 9..20 +
+// rows 11..20 whole (234 px); 46 of the 441 n1 pixels are computed by both halves (identical values).
 // Saves one launch and the 3.6 MB write + 7.2 MB read of n1 per 128 states against conv1_fwd + conv2_fwd.
-constexpr int CS_XROWS = 52;                                  // lower half; upper half uses 48
+constexpr int CS_XROWS = 56;                                  // upper half: x rows -2..53; lower half uses 52 (34..85)
 constexpr int CS_X_FLOATS = CS_XROWS * C1_PW * 4;             // 19712
-constexpr int CS_N1ROWS = 14;                                 // upper: n1 rows -1..10 (12 used); lower: 9..22
+constexpr int CS_N1ROWS = 14;                                 // upper: n1 rows -1..12; lower: 9..22
 constexpr int CS_N1_FLOATS = CS_N1ROWS * C2_PW * C1;          // 5376
-constexpr int CS_LDS_FLOATS = CS_X_FLOATS + CS_N1_FLOATS + 64 * 64 + 2 * 64 * 64;   // 37376 floats = 149,504 B
+constexpr int CS_LDS_FLOATS = CS_X_FLOATS + CS_N1_FLOATS + 64 * 64 + 2 * 64 * 64 + 256;   // 37632 floats = 150,528 B
+constexpr int CS_C2CUT = 60;                                  // conv2 pixels [0,60) | [60,121)
+
+// the m-th n1 pixel of a half's ragged list -> (row, col)
+__device__ __forceinline__ void cs_n1_pixel(int h, int m, int& row, int& col) {
+  if (h == 0) {
+    if (m < 11 * O1) { row = m / O1; col = m - row * O1; }
+    else { const int e = m - 11 * O1; row = 11 + e / 11; col = e - (e / 11) * 11; }
+  } else {
+    if (m < 24) { row = 9 + m / 12; col = 9 + m - (m / 12) * 12; }
+    else { const int e = m - 24; row = 11 + e / O1; col = e - (e / O1) * O1; }
+  }
+}
 
 template <bool TRAIN, bool U8>
 __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w1,
@@ -300,6 +332,7 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   float* n1l = cs_lds + CS_X_FLOATS;
   float* wl1 = n1l + CS_N1_FLOATS;
   float* wl2 = wl1 + 64 * 64;
+  int* pxmap = reinterpret_cast<int*>(wl2 + 2 * 64 * 64);    // ragged n1 pixel list: m -> (row << 8) | col
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int b = blockIdx.x >> 1, h = blockIdx.x & 1;
   if (b >= B) return;                                        // block-uniform guard: the grid is B * 2
@@ -307,54 +340,76 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   // memory, or the device-side frame queues): the intake gather happens here, in the staging loads
   const void* xs = src_off ? static_cast<const void*>(static_cast<const char*>(x) + src_off[b]) : x;
   const size_t sb = src_off ? 0 : (size_t)b;
-  // conv2 rows 0..4 | 5..10: then each half has <= 16 conv1 tiles and <= 16 conv2 items, one per wave
-  const int c2r0 = h ? 5 : 0, c2nr = h ? 6 : 5;              // conv2 output rows of this half
-  const int n1r0 = h ? 9 : 0, n1nr = h ? 12 : 11;            // n1 rows it needs (rows 9,10 are computed by both)
+  const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;     // conv2 pixels of this half
+  const int c2r0 = h ? 5 : 0;                                // first conv2 row it touches
+  const int n1r0 = h ? 9 : 0;                                // first n1 row it needs
+  const int n1npix = h ? 24 + 10 * O1 : 11 * O1 + 22;        // ragged n1 pixel list: 234 | 253
+  const int n1own0 = h ? 11 : 0, n1own1 = h ? O1 : 11;       // TRAIN: n1 rows this half stores (each row exactly once)
   const int n1org = 2 * c2r0 - 1;                            // n1 row held by LDS image row 0
-  const int xr0 = 4 * n1r0 - 2, xnr = 4 * n1nr + 4;          // x rows it needs (48 / 52)
-  // ---- stage x rows (zero padded), W1, W2; clear the n1 image.  All global loads are issued before the
-  // first LDS store, so the block pays one memory round trip.
-  const int npx = xnr * C1_PW;                               // <= 4576 pixels -> at most 5 per thread
+  const int xr0 = 4 * n1r0 - 2, xnr = h ? 52 : 56;           // x rows it needs
+  // ---- stage x rows (zero padded) and W1, clear the n1 image.  Every global load is issued before anything waits, so
+  // the block pays one memory round trip.  f32 states go global -> LDS directly (LDS-DMA: no VGPR pass, no ds_write; the
+  // image is linear in idx, so a wave's 64 pixels are 1 KB contiguous = wave base + lane * 16, and the padding cells,
+  // which no DMA lane writes, are zeroed by ordinary stores); uint8 frames are converted in registers on the way.
+  // W2 is not needed before conv2: its loads are in flight too, but it goes to LDS behind this wave's conv1 tile, under
+  // the other waves' MFMAs.
+  const int npx = xnr * C1_PW;                               // <= 4928 pixels -> at most 5 per thread
+  GA3C_STAMP(0);
   f32x4 sx[5], sw1, sw2[2];
+  sw1 = ld4(w1 + 4 * threadIdx.x);                           // W1[256][16] = 1024 float4 (first: it is stored first)
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int idx = threadIdx.x + 1024 * i;
     const int row = idx / C1_PW, col = idx - row * C1_PW;
     const int yy = xr0 + row, xx = col - 2;
     const bool ok = idx < npx && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-    sx[i] = ok ? load_px<U8>(xs, sb, yy * IMG + xx) : zero4();
+    if (!U8) {
+      float* dst = img + (size_t)(idx - lane) * 4;           // wave-uniform
+      if (ok)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const float*>(xs) + sb * XS + (size_t)(yy * IMG + xx) * 4),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      else if (idx < npx)
+        *reinterpret_cast<f32x4*>(&img[idx * 4]) = zero4();
+    } else {
+      sx[i] = ok ? load_px<U8>(xs, sb, yy * IMG + xx) : zero4();
+    }
   }
-  sw1 = ld4(w1 + 4 * threadIdx.x);                           // W1[256][16] = 1024 float4
   sw2[0] = ld4(w2 + 4 * threadIdx.x);                        // W2[256][32] = 2048 float4
   sw2[1] = ld4(w2 + 4 * (threadIdx.x + 1024));
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int idx = threadIdx.x + 1024 * i;
-    if (idx < npx) *reinterpret_cast<f32x4*>(&img[idx * 4]) = sx[i];
+  // nothing in the next two statements depends on the loads: they run while the loads are in flight
+  for (int idx4 = threadIdx.x; idx4 < CS_N1_FLOATS / 4; idx4 += 1024) *reinterpret_cast<f32x4*>(&n1l[idx4 * 4]) = zero4();
+  if (threadIdx.x < 256) {                                   // the divisions of the ragged map, once per pixel
+    int row, col;
+    cs_n1_pixel(h, threadIdx.x < n1npix ? threadIdx.x : 0, row, col);
+    pxmap[threadIdx.x] = (row << 8) | col;
   }
+  GA3C_STAMP(1);
   {
     const int idx4 = threadIdx.x, k = idx4 >> 2, n = (idx4 & 3) * 4;
     *reinterpret_cast<f32x4*>(&wl1[((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + n]) = sw1;
   }
+  if (U8) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx4 = threadIdx.x + 1024 * i, k = idx4 >> 3, n4 = (idx4 & 7) * 4;
-    *reinterpret_cast<f32x4*>(&wl2[(n4 >> 4) * 4096 + ((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + (n4 & 15)]) = sw2[i];
+    for (int i = 0; i < 5; ++i) {
+      const int idx = threadIdx.x + 1024 * i;
+      if (idx < npx) *reinterpret_cast<f32x4*>(&img[idx * 4]) = sx[i];
+    }
   }
-  for (int idx4 = threadIdx.x; idx4 < CS_N1_FLOATS / 4; idx4 += 1024) *reinterpret_cast<f32x4*>(&n1l[idx4 * 4]) = zero4();
-  __syncthreads();
+  GA3C_STAMP(2);
+  GA3C_STAMP(3);
+  __syncthreads();                                           // (waits for the DMA too: vmcnt(0) precedes the barrier)
+  GA3C_STAMP(4);
   // ---- conv1 over the half's n1 pixels, result into the LDS image (and to HBM when training)
   {
     float wr[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) wr[j] = wl1[j * 64 + lane];
     const float bv = b1[r];
-    const int npix = n1nr * O1, ntile = (npix + 15) >> 4;
+    const int ntile = (n1npix + 15) >> 4;                    // 15 | 16: one tile per wave
     for (int tile = wv; tile < ntile; tile += 16) {
-      const int ml = tile * 16 + r;
-      const int mm = ml < npix ? ml : 0;
-      const int il = mm / O1, j = mm - il * O1;
-      const float* base = img + ((4 * il) * C1_PW + 4 * j + g) * 4;
+      const int e = pxmap[tile * 16 + r];
+      const int row = e >> 8, col = e & 255;
+      const float* base = img + ((4 * (row - n1r0)) * C1_PW + 4 * col + g) * 4;
       f32x4 a[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 1) * C1_PW + (s & 1) * 4) * 4);
@@ -367,29 +422,37 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
           acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
         }
       }
+      const int4 e4 = *reinterpret_cast<const int4*>(&pxmap[tile * 16 + 4 * g]);
+      const int em[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int mr = tile * 16 + 4 * g + q;
-        if (mr < npix) {
-          const int ir = mr / O1, jr = mr - ir * O1;
+        if (tile * 16 + 4 * g + q < n1npix) {
+          const int ir = em[q] >> 8, jr = em[q] & 255;
           const float val = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
-          n1l[((n1r0 + ir - n1org) * C2_PW + jr + 1) * C1 + r] = val;
-          if (TRAIN) n1[((size_t)b * P1 + (n1r0 + ir) * O1 + jr) * C1 + r] = val;
+          n1l[((ir - n1org) * C2_PW + jr + 1) * C1 + r] = val;
+          if (TRAIN && ir >= n1own0 && ir < n1own1) n1[((size_t)b * P1 + ir * O1 + jr) * C1 + r] = val;
         }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx4 = threadIdx.x + 1024 * i, k = idx4 >> 3, n4 = (idx4 & 7) * 4;
+    *reinterpret_cast<f32x4*>(&wl2[(n4 >> 4) * 4096 + ((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + (n4 & 15)]) = sw2[i];
+  }
+  GA3C_STAMP(5);
   __syncthreads();
-  // ---- conv2 from the LDS image: items = (16-pixel tile, 16-column half)
+  GA3C_STAMP(6);
+  // ---- conv2 from the LDS image: items = (16-pixel tile, 16-column half), 8 per workgroup
   {
-    const int npix = c2nr * O2, nitem = 2 * ((npix + 15) >> 4);
+    const int nitem = 2 * ((c2npix + 15) >> 4);
     for (int item = wv; item < nitem; item += 16) {
       const int tile = item >> 1, hh = item & 1;
       const float* wf = wl2 + hh * 4096;
       const int ml = tile * 16 + r;
-      const int mm = ml < npix ? ml : 0;
-      const int i2 = mm / O2, j2 = mm - i2 * O2;
-      const float* base = n1l + ((2 * i2) * C2_PW + 2 * j2) * C1 + 4 * g;
+      const int qq = q0 + (ml < c2npix ? ml : 0);
+      const int i2 = qq / O2, j2 = qq - i2 * O2;
+      const float* base = n1l + ((2 * (i2 - c2r0)) * C2_PW + 2 * j2) * C1 + 4 * g;
       f32x4 a[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 2) * C2_PW + (s & 3)) * C1);
@@ -406,10 +469,11 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int mr = tile * 16 + 4 * g + q;
-        if (mr < npix) n2[(size_t)b * FLAT + ((size_t)c2r0 * O2 + mr) * C2 + hh * 16 + r] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
+        if (mr < c2npix) n2[(size_t)b * FLAT + (size_t)(q0 + mr) * C2 + hh * 16 + r] = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
       }
     }
   }
+  GA3C_STAMP(7);
 }
 
 // ------------------------------------------------------------------ dense1 weight packing
@@ -532,6 +596,15 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
     for (int o = 0; o < AMAX; ++o) wreg[q][o] = o < h.A ? wp[q * h.A + o] : 0.f;
   const f32x4 wv4 = ld4(h.wv + 4 * lane);
   f32x4 d = ld4(h.bd + 4 * lane);
+  // everything the tail needs is requested now, with the slab loads, not after the reductions (one round trip, not three)
+  const bool mine = lane < h.A;
+  const float bp_mine = mine ? h.bp[lane] : 0.f;
+  const float bv0 = h.bv[0];
+  float y = 0.f, a = 0.f;
+  if (TRAIN) {
+    y = h.y_r[b];
+    a = mine ? h.act[(size_t)b * h.A + lane] : 0.f;
+  }
   const float* pp = h.part + (size_t)b * HID + 4 * lane;
   const size_t kstride = (size_t)h.B * HID;
   {   // dense_ks() picks at most 22 slices: all of them in flight at once, summed in slice order
@@ -545,7 +618,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   for (int q = 0; q < 4; ++q) d[q] = fmaxf(d[q], 0.f);
   *reinterpret_cast<f32x4*>(h.d1 + (size_t)b * HID + 4 * lane) = d;
 
-  const float v = wave_sum(d[0] * wv4[0] + d[1] * wv4[1] + d[2] * wv4[2] + d[3] * wv4[3]) + h.bv[0];
+  const float v = wave_sum(d[0] * wv4[0] + d[1] * wv4[1] + d[2] * wv4[2] + d[3] * wv4[3]) + bv0;
   float zpart[AMAX];
 #pragma unroll
   for (int o = 0; o < AMAX; ++o) zpart[o] = d[0] * wreg[0][o] + d[1] * wreg[1][o] + d[2] * wreg[2][o] + d[3] * wreg[3][o];
@@ -556,8 +629,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   float zmine = -INFINITY;
 #pragma unroll
   for (int o = 0; o < AMAX; ++o)
-    if (lane == o && o < h.A) zmine = zpart[o] + h.bp[o];
-  const bool mine = lane < h.A;
+    if (lane == o && o < h.A) zmine = zpart[o] + bp_mine;
   const float zmax = wave_max(zmine);
   const float e = mine ? expf(zmine - zmax) : 0.f;
   const float esum = wave_sum(e);
@@ -570,9 +642,7 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   }
   if (lane == 0) h.v[b] = v;
   if (TRAIN) {
-    const float y = h.y_r[b];
     const float adv = y - v;
-    const float a = mine ? h.act[(size_t)b * h.A + lane] : 0.f;
     float dz, c1, c2;
     if (h.log_softmax) {
       const float ls = mine ? (zmine - zmax) - logf(esum) : 0.f;
