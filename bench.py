@@ -301,8 +301,8 @@ def main():
     if rank == 0:
         kernels = {}
         iters = 50
-        for name in ("conv_stack_fwd", "conv1_fwd", "conv2_fwd", "dense1_fwd", "heads", "dense1_dw", "dense1_dx", "dense1_bwd", "conv2_dw",
-                     "conv2_dx", "conv2_bwd", "conv1_dw", "slab_reduce", "rmsprop"):
+        for name in ("conv_stack_fwd", "conv1_fwd", "conv2_fwd", "dense1_fwd", "heads", "dense1_dw", "dense1_dx", "dense1_bwd", "dense1_bwd_tile", "conv2_dw",
+                     "conv2_dx", "conv1_dw", "slab_reduce", "rmsprop"):
             nat.check(lib.ga3c_net_time_kernel(h, name.encode(), B, 5, nat.C.byref(ev_ms)), name)
             nat.check(lib.ga3c_net_time_kernel(h, name.encode(), B, iters, nat.C.byref(ev_ms)), name)
             kernels[name] = ev_ms.value / iters * 1e3          # microseconds per launch

@@ -175,6 +175,7 @@ struct ga3c_net {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
+  int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
   bool graphs = false;                 // GA3C_GRAPHS=1: prediction steps replayed as hipGraphs.  Off by default: on ROCm 7.2 a
                                        // 4-kernel graph launch costs ~6 us MORE per step than four plain launches and
                                        // two lanes lose 10 % of their overlap (profiles/README.md, round 1)
@@ -273,14 +274,21 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   return GA3C_OK;
 }
 
-int launch_backward(ga3c_net* net, TrainLane& t, const float* th, int B) {
+int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B) {
   const int A = net->A;
+  const float* th = net->theta[idx];
   hipStream_t st = t.st;
   float* g = t.grad;
   HeadBwdArgs hb;
   hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
   hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV; hb.g_bv = g + OFF_BV; hb.losses = t.losses;
-  {
+  if (B <= net->d1b_tile_max) {
+    Dense1TileArgs d;
+    d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
+    d.hb = hb;
+    d.role_blocks = A + 2 < 14 ? A + 2 : 14;       // 242 tiles + the roles stay within one round of workgroups on 256 CUs
+    hipLaunchKernelGGL(dense1_bwd_tile_kernel, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+  } else {
     Dense1BwdArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
     d.hb = hb; d.dw_gx = FLAT / 32 + A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
@@ -291,7 +299,7 @@ int launch_backward(ga3c_net* net, TrainLane& t, const float* th, int B) {
   const int nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
   // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
   hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
-  hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 4), dim3(256), 0, st, t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+  hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
   const int nch1 = B * 7 < 512 ? B * 7 : 512;  // workgroups = partial slabs
   if (t.f.x_u8)
     hipLaunchKernelGGL(conv1_dw_kernel<true>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
@@ -432,7 +440,7 @@ int train_grads(ga3c_net* net, TrainLane& t, int B, float beta) {
     idx = net->latest;   // the newest weights: written by this same stream (synchronous mode) or in place (Hogwild)
   }
   CHK(launch_forward(net, t.f, idx, B, t.st, true, &t, beta));
-  CHK(launch_backward(net, t, net->theta[idx], B));
+  CHK(launch_backward(net, t, idx, B));
   return GA3C_OK;
 }
 
@@ -790,6 +798,15 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   net->cfg = *cfg;
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
+  if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense1_bwd_tile_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) {
+      delete net;
+      return fail(GA3C_EHIP, "cannot reserve LDS for dense1_bwd_tile_kernel: %s", hipGetErrorString(e));
+    }
+  }
   if (net->fused_conv) {
     const int lds = (int)(CS_LDS_FLOATS * sizeof(float));
     const void* fns[4] = {reinterpret_cast<const void*>(&conv_stack_fwd_kernel<true, true>),
@@ -832,7 +849,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   } while (0)
   for (int i = 0; i < 2; ++i) {
     TRY(dmalloc(&net->theta[i], (size_t)net->n));
-    TRY(dmalloc(&net->theta_pk[i], (size_t)FLAT * HID));
+    TRY(dmalloc(&net->theta_pk[i], (size_t)PK_FLOATS));
     TRYHIP(hipEventCreateWithFlags(&net->theta_ready[i], hipEventDisableTiming));
   }
   TRY(dmalloc(&net->grad, (size_t)net->n));
@@ -950,6 +967,8 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
   if (which == 0) {
     hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, net->tr.st, net->theta[net->latest] + OFF_WD,
                        net->theta_pk[net->latest]);
+    hipLaunchKernelGGL(pack_w2dx_kernel, dim3(32), dim3(256), 0, net->tr.st, net->theta[net->latest] + OFF_W2,
+                       net->theta_pk[net->latest] + PK_W2DX);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(net->tr.st));
   }
@@ -1604,7 +1623,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "conv2_dw") {
       TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
-      TL(conv2_dx_kernel, dim3(B, 4), t.dn2, th + OFF_W2, t.f.n1, t.dn1, B);
+      hipExtLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, t.st, t.ev0, t.ev1, 0, t.dn2, net->theta_pk[net->latest] + PK_W2DX, t.f.n1, t.dn1, B);
     } else if (k == "dense1_dw") {
       HeadBwdArgs hb;
       hb.B = B; hb.A = net->A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
@@ -1620,12 +1639,14 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.dw_gx = FLAT / 32 + net->A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
       d.dx_mt = dense_dx_mt(B);
       TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4)), d);
-    } else if (k == "conv2_bwd") {
-      Conv2BwdArgs c;
-      c.n1 = t.f.n1; c.dn2 = t.dn2; c.w2 = th + OFF_W2; c.slab2 = t.slab2; c.dn1 = t.dn1; c.B = B;
-      c.dw_gx = B < 256 ? B : 256; c.dw_blocks = 4 * c.dw_gx;
-      c.dx_gx = B;
-      TL(conv2_bwd_kernel, dim3(c.dw_blocks + 4 * c.dx_gx), c);
+    } else if (k == "dense1_bwd_tile") {
+      Dense1TileArgs d;
+      d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
+      d.hb.B = B; d.hb.A = net->A; d.hb.d1 = t.f.d1; d.hb.dz = t.dz; d.hb.dv = t.dv; d.hb.lossrow = t.lossrow;
+      d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
+      d.role_blocks = net->A + 2 < 14 ? net->A + 2 : 14;
+      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
+                            t.ev0, t.ev1, 0, d);
     } else if (k == "heads") {
       HeadArgs h;
       memset(&h, 0, sizeof h);

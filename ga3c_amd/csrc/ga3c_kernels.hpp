@@ -476,6 +476,26 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   GA3C_STAMP(7);
 }
 
+// ------------------------------------------------------------------ conv12/w packed for conv2_dx
+// conv2_dx contracts dn2 with the 128 x 16 sub-matrix of W2 that belongs to an output-pixel parity class (py, px); its
+// B fragments, in the order the MFMAs consume them, are a permutation of W2's 8192 elements: element (u, v, c, o) of
+// W2[4,4,16,32] goes to class (1 - u%2, 1 - v%2), fragment j = s*4 + t with s = (u/2)*4 + (v/2)*2 + o/16, t = o%4,
+// lane = ((o%16)/4)*16 + c.  The packed copy lives behind dense1's packed copy (pk + FLAT*HID) and is kept current by
+// rmsprop_kernel / pack_w2dx_kernel, so a workgroup stages a class with ONE 16-byte load per thread.
+constexpr int64_t PK_W2DX = (int64_t)FLAT * HID;             // offset of the packed conv12/w inside the pk buffer
+constexpr int PK_FLOATS = FLAT * HID + 256 * 32;
+__host__ __device__ inline int w2dx_packed_index(int i) {   // i = index into W2[256][32] = ((u*4+v)*16 + c)*32 + o
+  const int o = i & 31, k = i >> 5, c = k & 15, uv = k >> 4, u = uv >> 2, v = uv & 3;
+  const int cls = (1 - (u & 1)) * 2 + (1 - (v & 1));
+  const int s = ((u >> 1) << 2) | ((v >> 1) << 1) | (o >> 4);
+  const int j = s * 4 + (o & 3), ln = ((o & 15) >> 2) * 16 + c;
+  return cls * 2048 + j * 64 + ln;
+}
+__global__ __launch_bounds__(256) void pack_w2dx_kernel(const float* __restrict__ w2, float* __restrict__ pk2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 256 * 32) pk2[w2dx_packed_index(i)] = w2[i];
+}
+
 // ------------------------------------------------------------------ dense1 weight packing
 // pk[(s*256 + n)*16 + kk] = Wd[16 s + kk][n]: the B-operand fragment order of dense1_fwd, so that a lane's
 // four k values of a step are one 16-byte load and a wave instruction reads 1 KB contiguously.
@@ -985,43 +1005,14 @@ __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, cons
 constexpr int C2DX_DN = 12 * 12 * C2;       // padded dn2 image: (i+1, j+1), 4608 floats
 constexpr int C2DX_W = 32 * 64;             // weight fragments of one class
 
+// the 7-8 tiles of parity class (PY, PX) of one sample, dealt to the 4 waves of a wave group (wg = wave index in the group)
 template <int PY, int PX>
-__device__ __forceinline__ void conv2_dx_class(const float* __restrict__ dn2, const float* __restrict__ w,
-                                               const float* __restrict__ n1, float* __restrict__ dn1, int b,
-                                               float* __restrict__ dnl, float* __restrict__ wl) {
+__device__ __forceinline__ void conv2_dx_tiles(const float* __restrict__ dnl, const float* __restrict__ wl,
+                                               const float* __restrict__ n1b, float* __restrict__ d1b, int wg) {
   constexpr int NY = PY ? 10 : 11, NX = PX ? 10 : 11, CNT = NY * NX;
-  constexpr int PU = 1 - PY, PV = 1 - PX;
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  // ---- stage: padded dn2 image (1152 float4) and the class's weight fragments (2048 floats)
-  const float* db = dn2 + (size_t)b * FLAT;
-  f32x4 sd[5];
-  float sw[8];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int idx = threadIdx.x + 256 * i;                 // float4 index into [12][12][8]
-    const int pi = idx >> 3, pr = pi / 12, pc = pi - pr * 12;
-    const bool ok = idx < C2DX_DN / 4 && pr >= 1 && pc >= 1;
-    sd[i] = ok ? ld4(db + ((pr - 1) * O2 + (pc - 1)) * C2 + (idx & 7) * 4) : zero4();
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int e = threadIdx.x + 256 * k;                   // (j = s*4+t, lane)
-    const int j = e >> 6, ln = e & 63, s = j >> 2, t = j & 3;
-    const int u = PU + 2 * (s >> 2), v = PV + 2 * ((s >> 1) & 1);
-    sw[k] = w[((u * 4 + v) * 16 + (ln & 15)) * C2 + (s & 1) * 16 + 4 * (ln >> 4) + t];
-  }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int idx = threadIdx.x + 256 * i;
-    if (idx < C2DX_DN / 4) *reinterpret_cast<f32x4*>(&dnl[idx * 4]) = sd[i];
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) wl[threadIdx.x + 256 * k] = sw[k];
-  __syncthreads();
   constexpr int NTILE = (CNT + 15) / 16;
-  const float* n1b = n1 + (size_t)b * N1S;
-  float* d1b = dn1 + (size_t)b * N1S;
-  for (int tile = wv; tile < NTILE; tile += 4) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  for (int tile = wg; tile < NTILE; tile += 4) {
     const int mc = tile * 16 + r;
     const int mm = mc < CNT ? mc : 0;
     const int ya = mm / NX, xa = mm - ya * NX;
@@ -1055,19 +1046,226 @@ __device__ __forceinline__ void conv2_dx_class(const float* __restrict__ dn2, co
   }
 }
 
+// Workgroup (8 waves) = (sample, row parity PY): the sample's zero-bordered dn2 image is staged ONCE for the two column
+// parities, each with its own weight sub-matrix and its own group of 4 waves (one class per workgroup staged the image
+// four times per sample and left the kernel at 14 % MFMA utilisation).
+template <int PY>
+__device__ __forceinline__ void conv2_dx_pair(const float* __restrict__ dn2, const float* __restrict__ w,
+                                              const float* __restrict__ n1, float* __restrict__ dn1, int b,
+                                              float* __restrict__ dnl, float* __restrict__ wl) {
+  const float* db = dn2 + (size_t)b * FLAT;
+  f32x4 sd[3];
+  // w: the packed conv12/w (pack_w2dx_kernel order): classes (PY,0), (PY,1) are 2 x 2048 contiguous floats
+  const f32x4 sw0 = ld4(w + (PY * 2 + 0) * C2DX_W + 4 * threadIdx.x), sw1 = ld4(w + (PY * 2 + 1) * C2DX_W + 4 * threadIdx.x);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = threadIdx.x + 512 * i;                 // float4 index into [12][12][8]
+    const int pi = idx >> 3, pr = pi / 12, pc = pi - pr * 12;
+    const bool ok = idx < C2DX_DN / 4 && pr >= 1 && pc >= 1;
+    sd[i] = ok ? ld4(db + ((pr - 1) * O2 + (pc - 1)) * C2 + (idx & 7) * 4) : zero4();
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = threadIdx.x + 512 * i;
+    if (idx < C2DX_DN / 4) *reinterpret_cast<f32x4*>(&dnl[idx * 4]) = sd[i];
+  }
+  *reinterpret_cast<f32x4*>(&wl[4 * threadIdx.x]) = sw0;
+  *reinterpret_cast<f32x4*>(&wl[C2DX_W + 4 * threadIdx.x]) = sw1;
+  __syncthreads();
+  const float* n1b = n1 + (size_t)b * N1S;
+  float* d1b = dn1 + (size_t)b * N1S;
+  const int wv = threadIdx.x >> 6;
+  if (wv < 4) conv2_dx_tiles<PY, 0>(dnl, wl, n1b, d1b, wv);
+  else conv2_dx_tiles<PY, 1>(dnl, wl + C2DX_W, n1b, d1b, wv - 4);
+}
+
 __device__ __forceinline__ void conv2_dx_body(const float* __restrict__ dn2, const float* __restrict__ w,
                                               const float* __restrict__ n1, float* __restrict__ dn1, int B, int bx, int by,
                                               int gx) {
-  __shared__ __attribute__((aligned(16))) float c2dx_lds[C2DX_DN + C2DX_W];
+  __shared__ __attribute__((aligned(16))) float c2dx_lds[C2DX_DN + 2 * C2DX_W];
   float* dnl = c2dx_lds;
   float* wl = c2dx_lds + C2DX_DN;
   (void)gx;
   if (bx >= B) return;   // block-uniform guard: bx = sample
-  switch (by) {   // block-uniform: bx = sample, by = parity class
-    case 0: conv2_dx_class<0, 0>(dn2, w, n1, dn1, bx, dnl, wl); break;
-    case 1: conv2_dx_class<0, 1>(dn2, w, n1, dn1, bx, dnl, wl); break;
-    case 2: conv2_dx_class<1, 0>(dn2, w, n1, dn1, bx, dnl, wl); break;
-    default: conv2_dx_class<1, 1>(dn2, w, n1, dn1, bx, dnl, wl); break;
+  if (by == 0) conv2_dx_pair<0>(dn2, w, n1, dn1, bx, dnl, wl);   // block-uniform: by = row parity
+  else conv2_dx_pair<1>(dn2, w, n1, dn1, bx, dnl, wl);
+}
+
+// ------------------------------------------------------------------ dense1 backward, both gradients, LDS-tiled
+// Workgroup (16 waves) = 16 consecutive flat columns k0..k0+15 (242 workgroups = one round on the 256 CUs):
+//   dWd[k0+i][n]  = sum_b flat[b][k0+i] dd1[b][n]            M = 16, N = 256, contraction over the batch
+//   dn2[b][k0+i]  = 1[n2[b][k0+i] > 0] sum_n dd1[b][n] Wd[k0+i][n]      M = B, N = 16, contraction over 256
+// Both need ALL of dd1, which is what the two separate bodies above re-read from L2 once per wave (31 MB of fragment
+// loads at batch 128): here dd1 (a chunk of up to 128 rows, 128 KB), the 16 Wd rows (16 KB) and the 16 flat columns
+// (8 KB) go to LDS once per workgroup -- dd1 and Wd by LDS-DMA: a row is 1 KB = one wave instruction, so the rows can be
+// padded to 260 floats, which keeps the row-strided reads of the batch contraction (rows 4 apart for the lane groups of
+// a 32-lane LDS phase: 4 * 260 = 16 mod 32 banks) off each other; the flat columns through registers, transposed to
+// [column][row], so that a lane's four batch rows of a step are one 16-byte read -- and every MFMA operand is an LDS read.  Waves 0-7 own two 16-column tiles of dWd each (accumulated over the chunks), waves 8-15
+// one 16-row tile of dn2 each: 64 MFMAs per wave and chunk, four waves per SIMD.  Workgroup 0 also sums dd1 into dbd.
+// Blocks past the 242 tiles carry the head weight gradients and the loss sums.
+constexpr int D1B_ROWS = 128;                    // batch rows per chunk
+constexpr int D1B_DS = HID + 4;                  // padded row stride of dd1 / Wd in LDS (floats)
+constexpr int D1B_COLS = 16;                     // flat columns per workgroup
+constexpr int D1B_NS = D1B_ROWS + 4;             // row stride of the transposed flat columns [16][128] in LDS
+constexpr int D1B_LDS_FLOATS = D1B_ROWS * D1B_DS + D1B_COLS * D1B_DS + D1B_COLS * D1B_NS;   // 39552 floats = 158,208 B
+constexpr int D1B_TILES = FLAT / D1B_COLS;       // 242
+
+// head weight gradients / loss sums for a 1024-thread block (same arithmetic order as heads_bwd_role up to the fold width)
+__device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int role, float* lds) {
+  f32x4* sacc = reinterpret_cast<f32x4*>(lds);            // [16][64]
+  float* sh = lds + 16 * 64 * 4;                           // [16]
+  const int k = threadIdx.x, kq = k & 63, bg = k >> 6;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((k & 63) == 0) sh[bg] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i];
+    return t;
+  };
+  if (role <= h.A) {
+    const int o = role;
+    const bool isv = o == h.A;
+    f32x4 acc = zero4();
+    float bsum = 0.f;
+    for (int b0 = bg; b0 < h.B; b0 += 128) {
+      f32x4 dd[8];
+      float gh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int b = b0 + 16 * i;
+        const bool ok = b < h.B;
+        dd[i] = ok ? ld4(h.d1 + (size_t)b * HID + 4 * kq) : zero4();
+        gh[i] = ok ? (isv ? h.dv[b] : h.dz[(size_t)b * h.A + o]) : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += dd[i] * gh[i];
+    }
+    for (int b = k; b < h.B; b += 1024) bsum += isv ? h.dv[b] : h.dz[(size_t)b * h.A + o];
+    __syncthreads();                                        // a previous role's readers are done with sacc
+    sacc[bg * 64 + kq] = acc;
+    bsum = block_sum(bsum);                                 // its barriers also publish sacc
+    if (bg == 0) {
+      f32x4 tot = zero4();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tot += sacc[i * 64 + kq];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (isv) h.g_wv[4 * kq + q] = tot[q];
+        else h.g_wp[(size_t)(4 * kq + q) * h.A + o] = tot[q];
+      }
+    }
+    if (k == 0) {
+      if (isv) h.g_bv[0] = bsum; else h.g_bp[o] = bsum;
+    }
+  } else {
+    for (int c = 0; c < 3; ++c) {
+      float part = 0.f;
+      for (int b = k; b < h.B; b += 1024) part += h.lossrow[(size_t)b * 3 + c];
+      part = block_sum(part);
+      if (k == 0) h.losses[c] = part;
+    }
+  }
+}
+
+struct Dense1TileArgs {
+  const float* n2; const float* dd1; const float* wd; float* g_wd; float* g_bd; float* dn2; int B;
+  HeadBwdArgs hb; int role_blocks;
+};
+
+__global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float d1b_lds[];
+  if ((int)blockIdx.x >= D1B_TILES) {                       // block-uniform: the head roles, dealt round-robin
+    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide(a.hb, role, d1b_lds);
+    return;
+  }
+  float* dds = d1b_lds;                                     // [128][260]  dd1 rows of the chunk
+  float* wds = dds + D1B_ROWS * D1B_DS;                     // [16][260]   Wd rows k0..k0+15
+  float* n2s = wds + D1B_COLS * D1B_DS;                     // [16][132]   flat columns k0..k0+15 of the chunk's rows, transposed
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * D1B_COLS;
+  const int B = a.B;
+  f32x4 accw[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};   // dWd tiles n-tile 2 wv, 2 wv + 1 (waves 0-7), two chains each
+  float bs0 = 0.f, bs1 = 0.f;
+  for (int c0 = 0; c0 < B; c0 += D1B_ROWS) {
+    const int rows = B - c0 < D1B_ROWS ? B - c0 : D1B_ROWS;      // real rows of this chunk
+    const int prow = (rows + 15) & ~15;                          // padded to whole MFMA tiles
+    if (c0) __syncthreads();                                     // everyone is done reading the previous chunk
+    // ---- stage: one 1 KB wave instruction per dd1 / Wd row, one per 16 rows of the flat columns
+    for (int row = wv; row < prow; row += 16) {
+      if (row < rows)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dd1 + (size_t)(c0 + row) * HID + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(dds + row * D1B_DS), 16, 0, 0);
+      else
+        *reinterpret_cast<f32x4*>(&dds[row * D1B_DS + 4 * lane]) = zero4();
+    }
+    if (c0 == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wd + (size_t)(k0 + wv) * HID + 4 * lane),
+                                       (__attribute__((address_space(3))) void*)(wds + wv * D1B_DS), 16, 0, 0);
+    if (threadIdx.x < 4 * D1B_ROWS) {                            // thread -> (row tid/4, float4 tid%4), stored transposed
+      const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+      const f32x4 v = row < rows ? ld4(a.n2 + (size_t)(c0 + row) * FLAT + k0 + 4 * c) : zero4();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) n2s[(4 * c + j) * D1B_NS + row] = v[j];
+    }
+    __syncthreads();                                             // vmcnt(0) precedes the barrier: the DMA has landed
+    if (wv < 8) {
+      // ---- dWd: contraction over the chunk's rows, b = 16 s + 4 t + g
+      const int n0 = wv * 32;
+      for (int s = 0; s < prow / 16; ++s) {
+        const f32x4 av = ld4(n2s + r * D1B_NS + 16 * s + 4 * g);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int bb = 16 * s + 4 * g + t;
+          const float b0 = dds[bb * D1B_DS + n0 + r], b1 = dds[bb * D1B_DS + n0 + 16 + r];
+          bs0 += b0;
+          bs1 += b1;
+          accw[0][t & 1] = mfma(av[t], b0, accw[0][t & 1]);
+          accw[1][t & 1] = mfma(av[t], b1, accw[1][t & 1]);
+        }
+      }
+    } else {
+      // ---- dn2: one 16-row tile per wave, contraction over the 256 hidden units, k = 16 s + 4 g + t
+      const int m0 = (wv - 8) * 16;
+      if (m0 < prow) {                                           // wave-uniform
+        const float* ap = dds + (m0 + r) * D1B_DS + 4 * g;
+        const float* bp = wds + r * D1B_DS + 4 * g;
+        f32x4 acc0 = zero4(), acc1 = zero4();
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) {
+          const f32x4 a0 = ld4(ap + 16 * s), w0 = ld4(bp + 16 * s), a1 = ld4(ap + 16 * s + 16), w1 = ld4(bp + 16 * s + 16);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc0 = mfma(a0[t], w0[t], acc0);
+            acc1 = mfma(a1[t], w1[t], acc1);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = m0 + 4 * g + q;
+          if (row < rows)
+            a.dn2[(size_t)(c0 + row) * FLAT + k0 + r] = n2s[r * D1B_NS + row] > 0.f ? acc0[q] + acc1[q] : 0.f;
+        }
+      }
+    }
+  }
+  if (wv < 8) {
+    const int n0 = wv * 32;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        a.g_wd[(size_t)(k0 + 4 * g + q) * HID + n0 + ni * 16 + r] = accw[ni][0][q] + accw[ni][1][q];
+    if (blockIdx.x == 0) {
+      bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
+      bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
+      if (g == 0) {
+        a.g_bd[n0 + r] = bs0;
+        a.g_bd[n0 + 16 + r] = bs1;
+      }
+    }
   }
 }
 
@@ -1101,18 +1299,9 @@ __global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restric
                                                           float* __restrict__ part, int B) {
   conv2_dw_body(n1, dn2, part, B, blockIdx.x, blockIdx.y, gridDim.x);
 }
-__global__ __launch_bounds__(256) void conv2_dx_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void conv2_dx_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
                                                        const float* __restrict__ n1, float* __restrict__ dn1, int B) {
   conv2_dx_body(dn2, w, n1, dn1, B, blockIdx.x, blockIdx.y, gridDim.x);
-}
-struct Conv2BwdArgs {
-  const float* n1; const float* dn2; const float* w2; float* slab2; float* dn1; int B;
-  int dw_gx; int dw_blocks; int dx_gx;
-};
-__global__ __launch_bounds__(256, 2) void conv2_bwd_kernel(Conv2BwdArgs a) {
-  const int id = blockIdx.x;
-  if (id < a.dw_blocks) conv2_dw_body(a.n1, a.dn2, a.slab2, a.B, id % a.dw_gx, id / a.dw_gx, a.dw_gx);
-  else { const int j = id - a.dw_blocks; conv2_dx_body(a.dn2, a.w2, a.n1, a.dn1, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx); }
 }
 
 // ------------------------------------------------------------------ conv1 backward: dW1 partials
@@ -1297,7 +1486,8 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(const float* __restrict__ 
       for (int k = 1; k < 10; ++k) ti += (i >= tt.off[k]) ? 1 : 0;
       sc = scales[ti];
     }
-    rmsprop_one<CLIP, MOM>(i, theta_in, theta_out, ms, mom, grad, lr, one_minus_rho, mu, eps, sc);
+    const float tn = rmsprop_one<CLIP, MOM>(i, theta_in, theta_out, ms, mom, grad, lr, one_minus_rho, mu, eps, sc);
+    if (i >= OFF_W2 && i < OFF_B2) pk_out[PK_W2DX + w2dx_packed_index((int)(i - OFF_W2))] = tn;
   }
 }
 
