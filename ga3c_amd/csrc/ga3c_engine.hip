@@ -175,6 +175,7 @@ struct ga3c_net {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
+  bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
   bool graphs = false;                 // GA3C_GRAPHS=1: prediction steps replayed as hipGraphs.  Off by default: on ROCm 7.2 a
                                        // 4-kernel graph launch costs ~6 us MORE per step than four plain launches and
@@ -227,6 +228,28 @@ bool is_pinned(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
+// dense1 forward: the LDS-tiled kernel while its grid is one round of workgroups (one workgroup per CU: its LDS image
+// is 120-145 KB), the register-fragment kernel beyond
+int launch_dense1_fwd(ga3c_net* net, const float* flat, const float* pk, float* part, int B, int ks, hipStream_t st,
+                      hipEvent_t e0, hipEvent_t e1) {
+  const int max_steps = (KSTEPS_DENSE + ks - 1) / ks;
+  const int mt = B <= 128 ? 1 : 2;
+  const size_t lds = (size_t)d1f_lds_floats(mt, max_steps) * sizeof(float);
+  const int tile_blocks = dense1_fwd_blocks(B, ks, mt);
+  if (net->d1f_tile && max_steps <= 16 && lds <= 160 * 1024 && tile_blocks <= 256) {
+    if (mt == 1)
+      hipExtLaunchKernelGGL(dense1_fwd_tile_kernel<1>, dim3(tile_blocks), dim3(512), lds, st, e0, e1, 0, flat, pk, part, B, ks, max_steps);
+    else
+      hipExtLaunchKernelGGL(dense1_fwd_tile_kernel<2>, dim3(tile_blocks), dim3(512), lds, st, e0, e1, 0, flat, pk, part, B, ks, max_steps);
+  } else if (B <= 256) {
+    hipExtLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), dim3(256), 0, st, e0, e1, 0, flat, pk, part, B, ks, -1);
+  } else {
+    hipExtLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), dim3(256), 0, st, e0, e1, 0, flat, pk, part, B, ks, -1);
+  }
+  HIPCHK(hipGetLastError());
+  return GA3C_OK;
+}
+
 // ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
 int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, bool train,
                    const TrainLane* tl, float beta, float* out_p = nullptr, float* out_v = nullptr) {
@@ -251,12 +274,7 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
     hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
   }
   const int ks = dense_ks(B);
-  if (B <= 256)
-    hipLaunchKernelGGL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
-                       f.part, B, ks, -1);
-  else
-    hipLaunchKernelGGL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), dim3(256), 0, st, f.n2, net->theta_pk[idx],
-                       f.part, B, ks, -1);
+  CHK(launch_dense1_fwd(net, f.n2, net->theta_pk[idx], f.part, B, ks, st, nullptr, nullptr));
   HeadArgs h;
   memset(&h, 0, sizeof h);
   h.part = f.part; h.ks = ks; h.B = B; h.A = A;
@@ -799,6 +817,14 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
+  if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
+  for (const void* fn : {reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<1>), reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<2>)}) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      delete net;
+      return fail(GA3C_EHIP, "cannot reserve LDS for dense1_fwd_tile_kernel: %s", hipGetErrorString(e));
+    }
+  }
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense1_bwd_tile_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS * sizeof(float)));
@@ -1610,14 +1636,12 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
                             (const int64_t*)nullptr);
-    } else if (k == "dense1_fwd") {
-      const int ks = dense_ks(B);
-      if (B <= 256)
-        TL(dense1_fwd_kernel<1>, dim3(dense1_fwd_blocks(B, ks, 1)), t.f.n2, net->theta_pk[net->latest], t.f.part, B, ks,
-           -1);
-      else
-        TL(dense1_fwd_kernel<2>, dim3(dense1_fwd_blocks(B, ks, 2)), t.f.n2, net->theta_pk[net->latest], t.f.part, B, ks,
-           -1);
+    } else if (k == "dense1_fwd" || k == "dense1_fwd_frag") {
+      const bool keep = net->d1f_tile;
+      if (k == "dense1_fwd_frag") net->d1f_tile = false;
+      const int rc = launch_dense1_fwd(net, t.f.n2, net->theta_pk[net->latest], t.f.part, B, dense_ks(B), t.st, t.ev0, t.ev1);
+      net->d1f_tile = keep;
+      CHK(rc);
     } else if (k == "conv1_dw") {
       TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {

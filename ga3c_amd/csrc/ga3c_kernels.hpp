@@ -584,6 +584,68 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
       }
     }
 }
+// ---- the same partial products, LDS-tiled: a workgroup (8 waves) = (16*MT rows, 128 columns, one K slice of <= 16 steps).
+// Its whole working set -- the slice of the packed Wd (<= 128 KB, 1 KB per step and 16 columns = one LDS-DMA wave
+// instruction) and the rows' flat slice (1 KB per row, padded to 260 floats) -- is requested up front and lands in LDS
+// without a VGPR pass; the MFMAs then run from LDS without a memory wait between them.  The register-fragment kernel
+// above has one step of prefetch and pays a memory round trip per step (15 dependent round trips per slice).
+constexpr int D1F_AS = 16 * 16 + 4;              // LDS row stride of the flat slice (floats)
+__host__ __device__ constexpr int d1f_lds_floats(int mt, int max_steps) { return max_steps * 8 * 256 + 16 * mt * D1F_AS; }
+
+template <int MT>
+__global__ __launch_bounds__(512) void dense1_fwd_tile_kernel(const float* __restrict__ flat, const float* __restrict__ pk,
+                                                              float* __restrict__ part, int B, int ks_total, int max_steps) {
+  extern __shared__ __attribute__((aligned(16))) float d1f_lds[];
+  float* wls = d1f_lds;                                    // [step][8 column tiles][16 n][16 kk]
+  float* als = d1f_lds + max_steps * 8 * 256;              // [16*MT rows][260]
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int nrow = (B + 16 * MT - 1) / (16 * MT);
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int rb = j % nrow, yz = (j / nrow) * 8 + xcd;      // yz = ks * 2 + column half (blocks of one slice share an XCD)
+  if (yz >= ks_total * 2) return;
+  const int m0 = rb * 16 * MT, ks = yz >> 1, half = yz & 1;
+  const int s0 = (ks * KSTEPS_DENSE) / ks_total, s1 = ((ks + 1) * KSTEPS_DENSE) / ks_total, steps = s1 - s0;   // <= max_steps
+  // ---- stage (LDS-DMA): Wd slice, then the rows
+  for (int p = wv; p < steps * 8; p += 8) {
+    const int sl = p >> 3, nt = p & 7;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pk + ((size_t)(s0 + sl) * HID + half * 128 + nt * 16) * 16 + 4 * lane),
+                                     (__attribute__((address_space(3))) void*)(wls + p * 256), 16, 0, 0);
+  }
+  for (int row = wv; row < 16 * MT; row += 8) {
+    if (m0 + row < B) {                                     // wave-uniform
+      if (4 * lane < 16 * steps)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(flat + (size_t)(m0 + row) * FLAT + 16 * s0 + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(als + row * D1F_AS), 16, 0, 0);
+    } else {
+      *reinterpret_cast<f32x4*>(&als[row * D1F_AS + 4 * lane]) = zero4();
+    }
+  }
+  __syncthreads();                                           // vmcnt(0) precedes the barrier: the DMA has landed
+  f32x4 acc[MT][2];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) acc[mi][0] = acc[mi][1] = zero4();
+  const float* bp = wls + (wv * 16 + r) * 16 + 4 * g;
+  const float* ap = als + r * D1F_AS + 4 * g;
+  for (int sl = 0; sl < steps; ++sl) {
+    const f32x4 w = ld4(bp + sl * 8 * 256);
+    f32x4 a[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a[mi] = ld4(ap + mi * 16 * D1F_AS + 16 * sl);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) acc[mi][t & 1] = mfma(a[mi][t], w[t], acc[mi][t & 1]);
+  }
+  float* out = part + ((size_t)ks * B) * HID + half * 128 + wv * 16 + r;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int mr = m0 + mi * 16 + 4 * g + q;
+      if (mr < B) out[(size_t)mr * HID] = acc[mi][0][q] + acc[mi][1][q];
+    }
+}
+
 __host__ inline int dense1_fwd_blocks(int B, int ks_total, int mt) {
   const int nrow = (B + 16 * mt - 1) / (16 * mt);
   return 8 * nrow * ((ks_total * 2 + 7) / 8);
