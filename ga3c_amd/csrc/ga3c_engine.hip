@@ -101,6 +101,7 @@ struct TrainLane {
   float* grad = nullptr;    // this lane's gradient arena (lane 0: net->grad, the buffer RCCL all-reduces)
   bool owns_grad = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool exchanged = false;   // the gradients in `grad` have been all-reduced by the backward pass itself (overlapped exchange)
 };
 
 // K slices of dense1_fwd.  Its grid is (row blocks) x (2 column halves) x (slices), every slice a partial slab that
@@ -174,6 +175,12 @@ struct ga3c_net {
   std::atomic<int64_t> step{0};
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
+  // data-parallel exchange overlapped with the backward pass: dense1/w and everything behind it in the arena (98.8 % of
+  // the gradient) is final after the first backward kernel and is all-reduced on `cst` while the conv gradients are
+  // still being computed on the train stream; the 49 KB in front follow when they are done
+  hipStream_t cst = nullptr;
+  hipEvent_t ev_tail_ready = nullptr, ev_head_ready = nullptr, ev_comm_done = nullptr;
+  bool comm_overlap = true;            // GA3C_COMM_OVERLAP=0: one blocking all-reduce of the whole arena behind the backward pass
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
   bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
@@ -292,7 +299,9 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   return GA3C_OK;
 }
 
-int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B) {
+// overlap: the caller will apply the gradients right away (train, not compute_grads): start their all-reduce as soon as
+// each part of the arena is final; returns with the train stream already waiting for the exchange
+int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = false) {
   const int A = net->A;
   const float* th = net->theta[idx];
   hipStream_t st = t.st;
@@ -314,11 +323,18 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B) {
     const int dx_blocks = d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4);
     hipLaunchKernelGGL(dense1_bwd_kernel, dim3(d.dw_blocks + dx_blocks), dim3(256), 0, st, d);
   }
+  if (overlap) {
+    HIPCHK(hipEventRecord(net->ev_tail_ready, st));
+    HIPCHK(hipStreamWaitEvent(net->cst, net->ev_tail_ready, 0));
+    NCCLCHK(ncclAllReduce(g + OFF_WD, g + OFF_WD, (size_t)(net->n - OFF_WD), ncclFloat, ncclSum, net->comm, net->cst));
+  }
   const int nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
   // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
   hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
   hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
-  const int nch1 = B * 7 < 512 ? B * 7 : 512;  // workgroups = partial slabs
+  // workgroups = partial slabs.  Measured at batch 128 (gpurun_out sweep, round 2): 512 / 384 / 256 / 192 / 128 workgroups
+  // -> train step 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
+  const int nch1 = B * 7 < 256 ? B * 7 : 256;
   if (t.f.x_u8)
     hipLaunchKernelGGL(conv1_dw_kernel<true>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
   else
@@ -329,6 +345,13 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2);
   }
   HIPCHK(hipGetLastError());
+  if (overlap) {
+    HIPCHK(hipEventRecord(net->ev_head_ready, st));
+    HIPCHK(hipStreamWaitEvent(net->cst, net->ev_head_ready, 0));
+    NCCLCHK(ncclAllReduce(g, g, (size_t)OFF_WD, ncclFloat, ncclSum, net->comm, net->cst));
+    HIPCHK(hipEventRecord(net->ev_comm_done, net->cst));
+    HIPCHK(hipStreamWaitEvent(st, net->ev_comm_done, 0));
+  }
   return GA3C_OK;
 }
 
@@ -451,14 +474,15 @@ int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* o
 }
 
 // gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller)
-int train_grads(ga3c_net* net, TrainLane& t, int B, float beta) {
+int train_grads(ga3c_net* net, TrainLane& t, int B, float beta, bool will_apply = false) {
   int idx;
   {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
     idx = net->latest;   // the newest weights: written by this same stream (synchronous mode) or in place (Hogwild)
   }
   CHK(launch_forward(net, t.f, idx, B, t.st, true, &t, beta));
-  CHK(launch_backward(net, t, idx, B));
+  t.exchanged = will_apply && net->comm && net->comm_overlap && !net->hogwild && &t == &net->tr;
+  CHK(launch_backward(net, t, idx, B, t.exchanged));
   return GA3C_OK;
 }
 
@@ -472,8 +496,9 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
     net->step.fetch_add(1);
     return GA3C_OK;
   }
-  if (net->comm && net->world > 1)
+  if (net->comm && !t.exchanged)       // (train_grads has already exchanged the gradients when it knew a step would follow)
     NCCLCHK(ncclAllReduce(t.grad, t.grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
+  t.exchanged = false;
   std::unique_lock<std::shared_mutex> lk(net->wmu);
   const int idx = net->latest, other = 1 - idx;
   if (net->cur.load() != idx) {
@@ -918,6 +943,9 @@ int ga3c_net_destroy(ga3c_net* net) {
   (void)hipSetDevice(net->cfg.device);
   (void)hipDeviceSynchronize();
   if (net->comm) (void)ncclCommDestroy(net->comm);
+  if (net->cst) (void)hipStreamDestroy(net->cst);
+  for (hipEvent_t e : {net->ev_tail_ready, net->ev_head_ready, net->ev_comm_done})
+    if (e) (void)hipEventDestroy(e);
   for (Lane* L : net->lanes) {
     drop_graphs(*L);
     free_fwd(L->f);
@@ -1047,7 +1075,7 @@ int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float*
   TrainLane* t = take_train_lane(net);
   std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
   CHK(stage_train_inputs(net, *t, x, false, y_r, a, batch));
-  CHK(train_grads(net, *t, batch, beta));
+  CHK(train_grads(net, *t, batch, beta, true));
   CHK(train_apply(net, *t, learning_rate));
   return read_losses(net, *t, losses);
 }
@@ -1059,7 +1087,7 @@ int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const f
   TrainLane* t = take_train_lane(net);
   std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
   CHK(stage_train_inputs(net, *t, x, true, y_r, a, batch));
-  CHK(train_grads(net, *t, batch, beta));
+  CHK(train_grads(net, *t, batch, beta, true));
   CHK(train_apply(net, *t, learning_rate));
   return read_losses(net, *t, losses);
 }
@@ -1133,7 +1161,7 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   TrainLane& t = *tp;
   CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.f, t.st));
   CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta));
+  CHK(train_grads(net, t, batch, beta, true));
   CHK(train_apply(net, t, learning_rate));
   return read_losses(net, t, losses);
 }
@@ -1371,7 +1399,7 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
   std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
   TrainLane& t = *tp;
   CHK(stage_history_rows(net, t, agents, seqs, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta));
+  CHK(train_grads(net, t, batch, beta, true));
   CHK(train_apply(net, t, learning_rate));
   return read_losses(net, t, losses);
 }
@@ -1497,7 +1525,7 @@ int ga3c_net_train_resident(ga3c_net* net, int32_t batch, float learning_rate, f
   if (!net) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(train_grads(net, net->tr, batch, beta));
+  CHK(train_grads(net, net->tr, batch, beta, true));
   return train_apply(net, net->tr, learning_rate);
 }
 
@@ -1519,7 +1547,7 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
     if (mode == 0) {
       CHK(resident_predict_locked(net, batch));
     } else {
-      CHK(train_grads(net, net->tr, batch, beta));
+      CHK(train_grads(net, net->tr, batch, beta, true));
       CHK(train_apply(net, net->tr, learning_rate));
     }
   }
@@ -1643,7 +1671,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       net->d1f_tile = keep;
       CHK(rc);
     } else if (k == "conv1_dw") {
-      TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
+      TL(conv1_dw_kernel<false>, dim3(B * 7 < 256 ? B * 7 : 256), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {
       TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
@@ -1683,7 +1711,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       else if (net->A <= 24) TL((heads_kernel<false, 24>), dim3((B + 3) / 4), h);
       else TL((heads_kernel<false, 64>), dim3((B + 3) / 4), h);
     } else if (k == "slab_reduce") {
-      const int nch1 = B * 7 < 512 ? B * 7 : 512, nch2 = B < 256 ? B : 256;
+      const int nch1 = B * 7 < 256 ? B * 7 : 256, nch2 = B < 256 ? B : 256;
       SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
       SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
       hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2);
@@ -1758,6 +1786,10 @@ int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int3
   NCCLCHK(ncclCommInitRank(&net->comm, world, uid, rank));
   net->world = world;
   net->rank = rank;
+  net->comm_overlap = !(getenv("GA3C_COMM_OVERLAP") && atoi(getenv("GA3C_COMM_OVERLAP")) == 0);
+  HIPCHK(hipStreamCreateWithFlags(&net->cst, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&net->ev_tail_ready, &net->ev_head_ready, &net->ev_comm_done})
+    HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   return GA3C_OK;
 }
 

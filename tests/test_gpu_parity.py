@@ -189,11 +189,44 @@ def test_rccl_single_rank_communicator_allreduce_is_identity():
         import _native as nat
         nat.check(net._lib.ga3c_net_allreduce_grads(net._h), "allreduce")
         assert np.array_equal(net.get_arena(3), before)
-        net.learning_rate = 3e-4
-        net.train(x, y, a)                      # the train path with a communicator attached
-        assert np.all(np.isfinite(net.get_arena(0)))
+        # the train path with a communicator attached: the exchange is OVERLAPPED with the backward pass (dense1/w and
+        # the head gradients are all-reduced on a second stream while the conv gradients are still being computed); with
+        # one rank the sum is the identity, so the step must equal the step of a net without a communicator bit for bit
+        plain = Network("gpu:0", "dp_plain", 6, (84, 84, 4), max_batch=16, predict_lanes=1)
+        try:
+            for n in (net, plain):
+                n.set_arena(0, _flat(o.init_params(6), 6))
+                n.set_arena(1, np.ones(n.param_count, np.float32))
+                n.learning_rate, n.beta = 3e-4, 0.01
+                for _ in range(3):
+                    n.train(x, y, a)
+            assert np.array_equal(net.get_arena(0), plain.get_arena(0))
+            assert np.array_equal(net.get_arena(1), plain.get_arena(1))
+            assert np.array_equal(net.get_arena(3), plain.get_arena(3))
+        finally:
+            plain.close()
     finally:
         net.close()
+
+
+def test_rccl_blocking_exchange_equals_overlapped(monkeypatch):
+    """GA3C_COMM_OVERLAP=0 keeps the round-1 form (one all-reduce of the whole arena behind the backward pass)."""
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    _, x, a, y = _batch(12, 6, 31)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GA3C_COMM_OVERLAP", flag)
+        net = Network("gpu:0", "dp%s" % flag, 6, (84, 84, 4), max_batch=16, predict_lanes=1)
+        try:
+            net.comm_init(Network.make_comm_id(), 0, 1)
+            net.learning_rate, net.beta = 3e-4, 0.01
+            for _ in range(2):
+                net.train(x, y, a)
+            outs.append(net.get_arena(0))
+        finally:
+            net.close()
+    assert np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("cfg", [dict(USE_LOG_SOFTMAX=True), dict(MIN_POLICY=0.01), dict(USE_GRAD_CLIP=True, GRAD_CLIP_NORM=0.002),
