@@ -859,13 +859,6 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
-  for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CB_LDS_FLOATS * sizeof(float)));
-    if (e != hipSuccess) {
-      delete net;
-      return fail(GA3C_EHIP, "cannot reserve LDS for conv_bwd_kernel: %s", hipGetErrorString(e));
-    }
-  }
   for (const void* fn : {reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<1>), reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<2>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {

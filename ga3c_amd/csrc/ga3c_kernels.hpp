@@ -57,6 +57,11 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+// Pins a value in a register at this point of the program: an operand fetched from LDS ahead of time stays fetched ahead
+// of time (hipcc otherwise sinks the read down to its use, re-uses one register for all of them and waits lgkmcnt(0) in
+// front of every MFMA pair).
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -401,25 +406,33 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   GA3C_STAMP(4);
   // ---- conv1 over the half's n1 pixels, result into the LDS image (and to HBM when training)
   {
-    float wr[64];
-#pragma unroll
-    for (int j = 0; j < 64; ++j) wr[j] = wl1[j * 64 + lane];
     const float bv = b1[r];
     const int ntile = (n1npix + 15) >> 4;                    // 15 | 16: one tile per wave
     for (int tile = wv; tile < ntile; tile += 16) {
       const int e = pxmap[tile * 16 + r];
       const int row = e >> 8, col = e & 255;
       const float* base = img + ((4 * (row - n1r0)) * C1_PW + 4 * col + g) * 4;
-      f32x4 a[16];
+      // per pair of k-steps: 2 patch reads (16 B) + 8 filter fragments, fetched and pinned one pair ahead of their 8 MFMAs
+      f32x4 pa[2][2];
+      float pw[2][8];
+      auto load_pair = [&](int s, f32x4 (&a)[2], float (&w8)[8]) {
+        a[0] = ld4(base + ((s >> 1) * C1_PW + (s & 1) * 4) * 4);
+        a[1] = ld4(base + (((s + 1) >> 1) * C1_PW + ((s + 1) & 1) * 4) * 4);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 1) * C1_PW + (s & 1) * 4) * 4);
+        for (int k = 0; k < 8; ++k) w8[k] = wl1[(s * 4 + k) * 64 + lane];
+        pin(a[0]); pin(a[1]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pin(w8[k]);
+      };
       f32x4 acc0 = zero4(), acc1 = zero4();
+      load_pair(0, pa[0], pw[0]);
 #pragma unroll
       for (int s = 0; s < 16; s += 2) {
+        if (s + 2 < 16) load_pair(s + 2, pa[((s >> 1) + 1) & 1], pw[((s >> 1) + 1) & 1]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc0 = mfma(a[s][t], wr[s * 4 + t], acc0);
-          acc1 = mfma(a[s + 1][t], wr[(s + 1) * 4 + t], acc1);
+          acc0 = mfma(pa[(s >> 1) & 1][0][t], pw[(s >> 1) & 1][t], acc0);
+          acc1 = mfma(pa[(s >> 1) & 1][1][t], pw[(s >> 1) & 1][4 + t], acc1);
         }
       }
       const int4 e4 = *reinterpret_cast<const int4*>(&pxmap[tile * 16 + 4 * g]);
@@ -453,16 +466,26 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
       const int qq = q0 + (ml < c2npix ? ml : 0);
       const int i2 = qq / O2, j2 = qq - i2 * O2;
       const float* base = n1l + ((2 * (i2 - c2r0)) * C2_PW + 2 * j2) * C1 + 4 * g;
-      f32x4 a[16];
+      f32x4 pa[2][2];
+      float pw[2][8];
+      auto load_pair = [&](int s, f32x4 (&a)[2], float (&w8)[8]) {
+        a[0] = ld4(base + ((s >> 2) * C2_PW + (s & 3)) * C1);
+        a[1] = ld4(base + (((s + 1) >> 2) * C2_PW + ((s + 1) & 3)) * C1);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) a[s] = ld4(base + ((s >> 2) * C2_PW + (s & 3)) * C1);
+        for (int k = 0; k < 8; ++k) w8[k] = wf[(s * 4 + k) * 64 + lane];
+        pin(a[0]); pin(a[1]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pin(w8[k]);
+      };
       f32x4 acc0 = zero4(), acc1 = zero4();
+      load_pair(0, pa[0], pw[0]);
 #pragma unroll
       for (int s = 0; s < 16; s += 2) {
+        if (s + 2 < 16) load_pair(s + 2, pa[((s >> 1) + 1) & 1], pw[((s >> 1) + 1) & 1]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc0 = mfma(a[s][t], wf[(s * 4 + t) * 64 + lane], acc0);
-          acc1 = mfma(a[s + 1][t], wf[((s + 1) * 4 + t) * 64 + lane], acc1);
+          acc0 = mfma(pa[(s >> 1) & 1][0][t], pw[(s >> 1) & 1][t], acc0);
+          acc1 = mfma(pa[(s >> 1) & 1][1][t], pw[(s >> 1) & 1][4 + t], acc1);
         }
       }
       const float bv = b2[hh * 16 + r];
@@ -1025,19 +1048,31 @@ __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, cons
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&dnl[(threadIdx.x + 256 * i) * 4]) = sdn[i];
     __syncthreads();
     if (b + gx < B) fetch(b + gx);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    // operands of step s+1 are fetched and pinned in registers of their own before the MFMAs of step s
+    float oa[2][4], ob[2][4][2];
+    auto load_step = [&](int s, float (&a)[4], float (&bb)[4][2]) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int q = 16 * s + 4 * t + g;
         const int qc = q < P2 ? q : 0;                 // slots 121..127 carry dn2 = 0
         const int i = qc / O2, j = qc - i * O2;
-        const float a = img[((2 * i + u) * C2_PW + 2 * j + v) * C1 + r];
-        const float b0 = dnl[q * C2 + r], b1 = dnl[q * C2 + 16 + r];
-        bs0 += b0;
-        bs1 += b1;
-        acc0 = mfma(a, b0, acc0);
-        acc1 = mfma(a, b1, acc1);
+        a[t] = img[((2 * i + u) * C2_PW + 2 * j + v) * C1 + r];
+        bb[t][0] = dnl[q * C2 + r];
+        bb[t][1] = dnl[q * C2 + 16 + r];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { pin(a[t]); pin(bb[t][0]); pin(bb[t][1]); }
+    };
+    load_step(0, oa[0], ob[0]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s + 1 < 8) load_step(s + 1, oa[(s + 1) & 1], ob[(s + 1) & 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bs0 += ob[s & 1][t][0];
+        bs1 += ob[s & 1][t][1];
+        acc0 = mfma(oa[s & 1][t], ob[s & 1][t][0], acc0);
+        acc1 = mfma(oa[s & 1][t], ob[s & 1][t][1], acc1);
       }
     }
   }
@@ -1095,13 +1130,23 @@ __device__ __forceinline__ void conv2_dx_tiles(const float* __restrict__ dnl, co
     for (int s = 0; s < 8; ++s)
       a[s] = ld4(dnl + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
     f32x4 acc0 = zero4(), acc1 = zero4();
+    float wq[2][8];                                      // the 8 weight fragments of an s pair, one pair ahead
+    auto load_w = [&](int s, float (&w8)[8]) {
 #pragma unroll
-    for (int s = 0; s < 8; s += 2)
+      for (int k = 0; k < 8; ++k) w8[k] = wl[(s * 4 + k) * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pin(w8[k]);
+    };
+    load_w(0, wq[0]);
+#pragma unroll
+    for (int s = 0; s < 8; s += 2) {
+      if (s + 2 < 8) load_w(s + 2, wq[((s >> 1) + 1) & 1]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc0 = mfma(a[s][t], wl[(s * 4 + t) * 64 + lane], acc0);
-        acc1 = mfma(a[s + 1][t], wl[((s + 1) * 4 + t) * 64 + lane], acc1);
+        acc0 = mfma(a[s][t], wq[(s >> 1) & 1][t], acc0);
+        acc1 = mfma(a[s + 1][t], wq[(s >> 1) & 1][4 + t], acc1);
       }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (tile * 16 + 4 * g + q < CNT) d1b[off[q]] = mask[q] > 0.f ? acc0[q] + acc1[q] : 0.f;
@@ -1276,16 +1321,42 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     if (wv < 8) {
       // ---- dWd: contraction over the chunk's rows, b = 16 s + 4 t + g
       const int n0 = wv * 32;
-      for (int s = 0; s < prow / 16; ++s) {
-        const f32x4 av = ld4(n2s + r * D1B_NS + 16 * s + 4 * g);
+      // operands of step s+1 are fetched (and pinned in registers of their own) before the MFMAs of step s
+      f32x4 av[2];
+      float bw[2][4][2];
+      auto load_step = [&](int s, f32x4& a, float (&b)[4][2]) {
+        a = ld4(n2s + r * D1B_NS + 16 * s + 4 * g);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int bb = 16 * s + 4 * g + t;
-          const float b0 = dds[bb * D1B_DS + n0 + r], b1 = dds[bb * D1B_DS + n0 + 16 + r];
-          bs0 += b0;
-          bs1 += b1;
-          accw[0][t & 1] = mfma(av[t], b0, accw[0][t & 1]);
-          accw[1][t & 1] = mfma(av[t], b1, accw[1][t & 1]);
+          b[t][0] = dds[bb * D1B_DS + n0 + r];
+          b[t][1] = dds[bb * D1B_DS + n0 + 16 + r];
+        }
+        pin(a);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { pin(b[t][0]); pin(b[t][1]); }
+      };
+      const int nstep = prow / 16;
+      load_step(0, av[0], bw[0]);
+      for (int s = 0; s < nstep; s += 2) {
+        // two steps per trip so that the double buffer is indexed by constants
+        if (s + 1 < nstep) load_step(s + 1, av[1], bw[1]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bs0 += bw[0][t][0];
+          bs1 += bw[0][t][1];
+          accw[0][t & 1] = mfma(av[0][t], bw[0][t][0], accw[0][t & 1]);
+          accw[1][t & 1] = mfma(av[0][t], bw[0][t][1], accw[1][t & 1]);
+        }
+        if (s + 1 < nstep) {
+          if (s + 2 < nstep) load_step(s + 2, av[0], bw[0]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            bs0 += bw[1][t][0];
+            bs1 += bw[1][t][1];
+            accw[0][t & 1] = mfma(av[1][t], bw[1][t][0], accw[0][t & 1]);
+            accw[1][t & 1] = mfma(av[1][t], bw[1][t][1], accw[1][t & 1]);
+          }
         }
       }
     } else {
@@ -1295,13 +1366,19 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
         const float* ap = dds + (m0 + r) * D1B_DS + 4 * g;
         const float* bp = wds + r * D1B_DS + 4 * g;
         f32x4 acc0 = zero4(), acc1 = zero4();
+        f32x4 xa[2][2], xw[2][2];
+        auto load_pair = [&](int s, f32x4 (&a)[2], f32x4 (&w)[2]) {
+          a[0] = ld4(ap + 16 * s); w[0] = ld4(bp + 16 * s); a[1] = ld4(ap + 16 * s + 16); w[1] = ld4(bp + 16 * s + 16);
+          pin(a[0]); pin(w[0]); pin(a[1]); pin(w[1]);
+        };
+        load_pair(0, xa[0], xw[0]);
 #pragma unroll
         for (int s = 0; s < 16; s += 2) {
-          const f32x4 a0 = ld4(ap + 16 * s), w0 = ld4(bp + 16 * s), a1 = ld4(ap + 16 * s + 16), w1 = ld4(bp + 16 * s + 16);
+          if (s + 2 < 16) load_pair(s + 2, xa[((s >> 1) + 1) & 1], xw[((s >> 1) + 1) & 1]);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            acc0 = mfma(a0[t], w0[t], acc0);
-            acc1 = mfma(a1[t], w1[t], acc1);
+            acc0 = mfma(xa[(s >> 1) & 1][0][t], xw[(s >> 1) & 1][0][t], acc0);
+            acc1 = mfma(xa[(s >> 1) & 1][1][t], xw[(s >> 1) & 1][1][t], acc1);
           }
         }
 #pragma unroll
@@ -1413,21 +1490,40 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
     *reinterpret_cast<f32x4*>(&dnl[threadIdx.x * 4]) = sdn;
     __syncthreads();
     if (unit + (int)gridDim.x < nunits) fetch(unit + gridDim.x);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    // The 20 LDS operands of a step (4 pixel slots x (1 dn1 value + 4 patch values)) are read into registers of their
+    // own one step AHEAD of the 16 MFMAs that consume them: left to itself hipcc re-used one register pair for every
+    // read and put an lgkmcnt(0) wait in front of every second MFMA (LDS latency exposed 32 times per unit).
+    float av[2][4][4], bv[2][4];
+    auto load_step = [&](int s, float (&a)[4][4], float (&b)[4]) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int q = 16 * s + 4 * t + g;
         const int qc = q < C1_HB * O1 ? q : 0;          // slot 63 carries dn1 = 0
         const int il = qc / O1, j = qc - il * O1;
-        const float bval = dnl[q * C1 + r];
-        bs += bval;
+        b[t] = dnl[q * C1 + r];
         const float* ap = img + (4 * il) * (C1_PW * 4) + 16 * j + r;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const int mt = mg * 4 + mi;                   // u = mt>>1, vh = mt&1
-          acc[mi] = mfma(ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16], bval, acc[mi]);
+          a[t][mi] = ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16];
         }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pin(b[t]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) pin(a[t][mi]);
+      }
+    };
+    load_step(0, av[0], bv[0]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s + 1 < 4) load_step(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bs += bv[s & 1][t];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[mi] = mfma(av[s & 1][t][mi], bv[s & 1][t], acc[mi]);
       }
     }
   }
