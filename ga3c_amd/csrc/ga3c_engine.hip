@@ -336,7 +336,9 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
     // workgroups = partial slabs.  Measured at batch 128 (round 2): 512 / 384 / 256 / 192 / 128 workgroups -> train step
     // 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
-    nch1 = B * 7 < 256 ? B * 7 : 256;
+    // (uint8 states: 4-byte loads per pixel, the one-deep prefetch covers less of the longer chain: 512 there)
+    const int cap1 = t.f.x_u8 ? 512 : 256;
+    nch1 = B * 7 < cap1 ? B * 7 : cap1;
     if (t.f.x_u8)
       hipLaunchKernelGGL(conv1_dw_kernel<true>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
     else
