@@ -182,6 +182,7 @@ struct ga3c_net {
   hipEvent_t ev_tail_ready = nullptr, ev_head_ready = nullptr, ev_comm_done = nullptr;
   bool comm_overlap = true;            // GA3C_COMM_OVERLAP=0: one blocking all-reduce of the whole arena behind the backward pass
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
+  bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
   bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
   bool graphs = false;                 // GA3C_GRAPHS=1: prediction steps replayed as hipGraphs.  Off by default: on ROCm 7.2 a
@@ -329,7 +330,18 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     NCCLCHK(ncclAllReduce(g + OFF_WD, g + OFF_WD, (size_t)(net->n - OFF_WD), ncclFloat, ncclSum, net->comm, net->cst));
   }
   int nch1, nch2;
-  {
+  if (net->conv_bwd_fused && B <= 128) {   // one workgroup per CU: beyond one round the tail of the second costs more than the fusion saves
+    // conv2_dw + conv2_dx + conv1_dw of a sample half in ONE workgroup (conv_bwd_kernel): dn1 never leaves the chip between them
+    const int grid = 2 * B < 256 ? 2 * B : 256;     // (sample group, half); one slab pair per workgroup
+    const size_t lds = CB_LDS_FLOATS * sizeof(float);
+    if (t.f.x_u8)
+      hipLaunchKernelGGL(conv_bwd_kernel<true>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.xu8, t.f.n1, t.dn2,
+                         net->theta_pk[idx] + PK_W2DX, t.dn1, t.slab2, t.slab1, B);
+    else
+      hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.x, t.f.n1, t.dn2,
+                         net->theta_pk[idx] + PK_W2DX, t.dn1, t.slab2, t.slab1, B);
+    nch1 = nch2 = grid;
+  } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
     // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
     hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
@@ -848,6 +860,14 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
+  for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CB_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) {
+      delete net;
+      return fail(GA3C_EHIP, "cannot reserve LDS for conv_bwd_kernel: %s", hipGetErrorString(e));
+    }
+  }
   for (const void* fn : {reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<1>), reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<2>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
@@ -1696,6 +1716,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.dw_gx = FLAT / 32 + net->A + 2; d.dw_blocks = 2 * d.dw_gx; d.dx_gx = FLAT / 32;
       d.dx_mt = dense_dx_mt(B);
       TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4)), d);
+    } else if (k == "conv_bwd") {
+      hipExtLaunchKernelGGL(conv_bwd_kernel<false>, dim3(2 * B < 256 ? 2 * B : 256), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, t.f.n1, t.dn2, net->theta_pk[net->latest] + PK_W2DX, t.dn1, t.slab2,
+                            t.slab1, B);
     } else if (k == "dense1_bwd_tile") {
       Dense1TileArgs d;
       d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;

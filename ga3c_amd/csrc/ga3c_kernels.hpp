@@ -1538,6 +1538,271 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
   }
 }
 
+// ------------------------------------------------------------------ conv backward, all three gradients of a sample half
+// conv2_dw, conv2_dx and conv1_dw each work sample by sample and hand dn2 -> dn1 through HBM; as three launches they cost
+// three grids of load round trips and two kernel boundaries (6.9 + 6.2 + 9.0 us at batch 128).  Here a workgroup (16 waves)
+// = (sample, half) with the halves of conv_stack_fwd (conv2 pixels 60 | 61; n1 rows 0..10 | 11..20 owned):
+//   phase 1  dn1 rows it owns = the transposed conv of dn2, by parity class (conv2_dx_tiles' arithmetic), ReLU mask
+//            from the n1 image in LDS; the result stays in LDS (and goes to HBM once, for ga3c_net_fetch)
+//   phase 2  dW2 partial over its conv2 pixels: wave = (pair of patch positions, half of the 64 pixel slots): every
+//            (dn2, n1) operand fetch and its pixel -> (row, column) arithmetic feeds 4 MFMAs
+//   phase 3  dW1 partial over its n1 rows in bands of 3 rows: wave = (4 m-tiles, quarter of the band's 64 pixel slots),
+//            the blocking of conv1_dw_kernel; the x bands (16 padded rows, 22.5 KB) arrive by LDS-DMA two bands ahead
+//   (the first version gave every wave one m-tile / one position: one operand pair and one index computation per MFMA made
+//   phases 2 and 3 VALU-bound, 26.8 us against 22.9 us for the three launches; the K-split partial sums of the waves are
+//   folded through LDS once, after the last sample)
+// Everything else the sample needs -- the padded n1 image of the half, the zero-bordered dn2 image, the packed conv12/w
+// of the four parity classes -- is requested at the top with the first two x bands: one memory round trip per sample.
+// Partial dW2 / dW1 (+ bias tails) go to slab2 / slab1 in conv2_dw's / conv1_dw's layout; slab_reduce_kernel is unchanged.
+constexpr int CB_N1IMG = CS_N1ROWS * C2_PW * C1;             // 5376 floats
+constexpr int CB_DN2IMG = 12 * 12 * C2;                      // 4608
+constexpr int CB_W2 = 4 * C2DX_W;                            // 8192
+constexpr int CB_DN1 = 11 * O1 * C1;                         // 3696: owned n1 rows, [row][col][16]
+constexpr int CB_XBAND = C1_RIN * C1_PW * 4;                 // 5632 floats per band buffer
+constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + 2 * CB_XBAND;   // 33136 floats = 132,544 B
+
+template <bool U8>
+__global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__ x, const float* __restrict__ n1,
+                                                       const float* __restrict__ dn2, const float* __restrict__ w2pk,
+                                                       float* __restrict__ dn1, float* __restrict__ slab2,
+                                                       float* __restrict__ slab1, int B) {
+  extern __shared__ __attribute__((aligned(16))) float cb_lds[];
+  GA3C_STAMP(0);
+  float* n1img = cb_lds;                                     // [14][24][16]  n1 rows n1org .. n1org+13, cols -1..22
+  float* dnimg = n1img + CB_N1IMG;                           // [12][12][32]  dn2 (i+1, j+1), zero row / column 0
+  float* w2l = dnimg + CB_DN2IMG;                            // [4 classes][32][64]
+  float* dn1l = w2l + CB_W2;                                 // [<= 11 rows][21][16]
+  float* xb = dn1l + CB_DN1;                                 // 2 x [16][88][4]
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int h = blockIdx.x & 1, grp = blockIdx.x >> 1, ngrp = gridDim.x >> 1;
+  const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;   // conv2 pixels of this half
+  const int c2r0 = h ? 5 : 0, n1org = 2 * c2r0 - 1;          // n1 image row 0 holds n1 row n1org
+  const int r0 = h ? 11 : 0, nrows = h ? 10 : 11;            // n1 rows this half owns
+  const int nband = (nrows + C1_HB - 1) / C1_HB;             // 4
+  // ---- once per workgroup: the packed conv12/w, and zeros in every cell no DMA lane will ever write
+  for (int p = wv; p < CB_W2 / 256; p += 16)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w2pk + p * 256 + 4 * lane),
+                                     (__attribute__((address_space(3))) void*)(w2l + p * 256), 16, 0, 0);
+  for (int i = threadIdx.x; i < (CB_N1IMG + CB_DN2IMG) / 4; i += 1024) *reinterpret_cast<f32x4*>(&n1img[4 * i]) = zero4();
+  __syncthreads();
+  GA3C_STAMP(1);
+  f32x4 acc2[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};          // [position of the pair][column half]
+  f32x4 acc1[4] = {zero4(), zero4(), zero4(), zero4()};                 // [m-tile of the group]
+  float bs2a = 0.f, bs2b = 0.f, bs1 = 0.f;
+  auto stage_band = [&](int b, int k) {                      // x rows of band k of sample b -> xb[k & 1]
+    float* buf = xb + (k & 1) * CB_XBAND;
+    const int y_base = 4 * (r0 + C1_HB * k) - 2;
+    for (int idx = threadIdx.x; idx < C1_RIN * C1_PW; idx += 1024) {
+      const int row = idx / C1_PW, col = idx - row * C1_PW;
+      const int yy = y_base + row, xx = col - 2;
+      const bool ok = (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+      if (U8) {
+        *reinterpret_cast<f32x4*>(&buf[idx * 4]) = ok ? load_px<true>(x, b, yy * IMG + xx) : zero4();
+      } else if (ok) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const float*>(x) + (size_t)b * XS + (size_t)(yy * IMG + xx) * 4),
+                                         (__attribute__((address_space(3))) void*)(buf + (size_t)(idx - lane) * 4), 16, 0, 0);
+      } else {
+        *reinterpret_cast<f32x4*>(&buf[idx * 4]) = zero4();
+      }
+    }
+  };
+  for (int b = grp; b < B; b += ngrp) {
+    // ---- stage the sample: n1 image (cells of 64 B, 4 lanes each), dn2 image (cells of 128 B, 8 lanes each), x bands 0, 1
+    const float* n1b = n1 + (size_t)b * N1S;
+    const float* db = dn2 + (size_t)b * FLAT;
+    for (int i = threadIdx.x; i < CB_N1IMG / 4; i += 1024) {
+      const int cell = i >> 2, row = cell / C2_PW, col = cell - row * C2_PW;
+      const int yy = n1org + row, xx = col - 1;
+      if ((unsigned)yy < (unsigned)O1 && (unsigned)xx < (unsigned)O1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(n1b + (yy * O1 + xx) * C1 + 4 * (i & 3)),
+                                         (__attribute__((address_space(3))) void*)(n1img + (size_t)(i - lane) * 4), 16, 0, 0);
+    }
+    for (int i = threadIdx.x; i < CB_DN2IMG / 4; i += 1024) {
+      const int cell = i >> 3, pr = cell / 12, pc = cell - pr * 12;
+      if (pr >= 1 && pc >= 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((pr - 1) * O2 + (pc - 1)) * C2 + 4 * (i & 7)),
+                                         (__attribute__((address_space(3))) void*)(dnimg + (size_t)(i - lane) * 4), 16, 0, 0);
+    }
+    stage_band(b, 0);
+    stage_band(b, 1);
+    __syncthreads();                                         // vmcnt(0) precedes the barrier: everything has landed
+    GA3C_STAMP(2);
+    // ---- phase 1: dn1 rows r0 .. r0+nrows-1 by parity class (16 or 17 tiles of 32 MFMAs)
+    {
+      const int nye = h ? 5 : 6, nyo = 5;                    // even / odd rows among the owned ones
+      const int t0 = (nye * 11 + 15) >> 4, t1 = t0 + ((nye * 10 + 15) >> 4), t2 = t1 + ((nyo * 11 + 15) >> 4),
+                t3 = t2 + ((nyo * 10 + 15) >> 4);
+#pragma unroll 1
+      for (int tw = wv; tw < t3; tw += 16) {                 // wave-uniform
+        const int cls = tw < t0 ? 0 : (tw < t1 ? 1 : (tw < t2 ? 2 : 3));
+        const int tile = tw - (cls == 0 ? 0 : (cls == 1 ? t0 : (cls == 2 ? t1 : t2)));
+        const int py = cls >> 1, px = cls & 1, nx = px ? 10 : 11, ccnt = (py ? nyo : nye) * nx;
+        const int yfirst = r0 + ((r0 & 1) == py ? 0 : 1);    // first owned row of this parity
+        const float* wl = w2l + cls * C2DX_W;
+        const int mc = tile * 16 + r;
+        const int mm = mc < ccnt ? mc : 0;
+        const int ya = mm / nx, xa = mm - ya * nx;
+        const int y = yfirst + 2 * ya, xq = 2 * xa + px;
+        const int ih = (y + 1) >> 1, jh = (xq + 1) >> 1;
+        f32x4 a[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+          a[s] = ld4(dnimg + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
+        f32x4 c0 = zero4(), c1 = zero4();
+#pragma unroll
+        for (int s = 0; s < 8; s += 2)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            c0 = mfma(a[s][t], wl[(s * 4 + t) * 64 + lane], c0);
+            c1 = mfma(a[s + 1][t], wl[((s + 1) * 4 + t) * 64 + lane], c1);
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mr = tile * 16 + 4 * g + q;
+          if (mr < ccnt) {
+            const int ya2 = mr / nx, xa2 = mr - ya2 * nx;
+            const int y2 = yfirst + 2 * ya2, x2 = 2 * xa2 + px;
+            const float keep = n1img[((y2 - n1org) * C2_PW + x2 + 1) * C1 + r];
+            const float val = keep > 0.f ? c0[q] + c1[q] : 0.f;
+            dn1l[((y2 - r0) * O1 + x2) * C1 + r] = val;
+            dn1[(size_t)b * N1S + (y2 * O1 + x2) * C1 + r] = val;
+          }
+        }
+      }
+    }
+    GA3C_STAMP(3);
+    // ---- phase 2: dW2 partial over conv2 pixels q0 .. q0+c2npix-1 (slots to 64 carry dn2 = 0)
+    // wave = (positions 2*pp, 2*pp+1 -- same u, v and v+1 --, K half kh: steps 2*kh, 2*kh+1)
+    {
+      const int pp = wv & 7, kh = wv >> 3, u = pp >> 1, v0 = (pp & 1) * 2;
+#pragma unroll 1
+      for (int ss = 0; ss < 2; ++ss) {
+        float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int q = 16 * (2 * kh + ss) + 4 * t + g;
+          const bool ok = q < c2npix;
+          const int qq = q0 + (ok ? q : 0);
+          const int i2 = qq / O2, j2 = qq - i2 * O2;
+          const float* ap = n1img + ((2 * (i2 - c2r0) + u) * C2_PW + 2 * j2 + v0) * C1 + r;
+          a0[t] = ap[0];
+          a1[t] = ap[C1];
+          const float* bp = dnimg + (ok ? ((i2 + 1) * 12 + j2 + 1) * C2 : 0);      // cell (0,0) is zero
+          b0[t] = bp[r];
+          b1[t] = bp[16 + r];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { pin(a0[t]); pin(a1[t]); pin(b0[t]); pin(b1[t]); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bs2a += b0[t];
+          bs2b += b1[t];
+          acc2[0][0] = mfma(a0[t], b0[t], acc2[0][0]);
+          acc2[0][1] = mfma(a0[t], b1[t], acc2[0][1]);
+          acc2[1][0] = mfma(a1[t], b0[t], acc2[1][0]);
+          acc2[1][1] = mfma(a1[t], b1[t], acc2[1][1]);
+        }
+      }
+    }
+    GA3C_STAMP(4);
+    __syncthreads();                                         // dn1 of the half is complete in LDS
+    GA3C_STAMP(5);
+    // ---- phase 3: dW1 partial, band by band; wave = (m-tiles 4*mg .. 4*mg+3, K quarter kq: pixel slots 16*kq .. 16*kq+15)
+    for (int k = 0; k < nband; ++k) {
+      const float* img = xb + (k & 1) * CB_XBAND;
+      const int brow0 = C1_HB * k;                           // first owned-row index of the band
+      const int bpix = (nrows - brow0 < C1_HB ? nrows - brow0 : C1_HB) * O1;       // 63, or 42 / 21 in the last band
+      const int mg = wv & 3, kq = wv >> 2;
+      float av[4][4], bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int q = 16 * kq + 4 * t + g;
+        const bool ok = q < bpix;
+        const int qc = ok ? q : 0;
+        const int il = qc / O1, j = qc - il * O1;
+        bv[t] = ok ? dn1l[(brow0 * O1 + q) * C1 + r] : 0.f;
+        const float* ap = img + (4 * il) * (C1_PW * 4) + 16 * j + r;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int mt = mg * 4 + mi;                        // u = mt >> 1, v half = mt & 1
+          av[t][mi] = ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pin(bv[t]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) pin(av[t][mi]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bs1 += bv[t];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc1[mi] = mfma(av[t][mi], bv[t], acc1[mi]);
+      }
+      __syncthreads();                                       // band k has been read; band k+1 has landed
+      if (k + 2 < nband) stage_band(b, k + 2);
+    }
+    GA3C_STAMP(6);
+  }
+  // ---- fold the K-split partial sums of the waves through LDS (fixed order), then write this workgroup's slab pair
+  {
+    float* red = cb_lds;                                     // everything staged above is dead now: 16 waves x 1024 floats
+    __syncthreads();
+    f32x4* mine = reinterpret_cast<f32x4*>(red) + (size_t)wv * 256 + lane;
+    mine[0] = acc2[0][0]; mine[64] = acc2[0][1]; mine[128] = acc2[1][0]; mine[192] = acc2[1][1];
+    red[16 * 1024 + wv * 64 + lane] = bs2a;
+    red[17 * 1024 + wv * 64 + lane] = bs2b;
+    __syncthreads();
+    float* o2 = slab2 + (size_t)blockIdx.x * SLAB2;
+    if (wv < 8) {                                            // K halves kh = 0 (this wave) + kh = 1 (wave + 8)
+      const f32x4* other = reinterpret_cast<const f32x4*>(red) + (size_t)(wv + 8) * 256 + lane;
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int mt = 2 * wv + pi;                          // patch position = m-tile of conv2_dw's slab layout
+        const f32x4 s0 = acc2[pi][0] + other[128 * pi], s1 = acc2[pi][1] + other[128 * pi + 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o2[(mt * 16 + 4 * g + q) * C2 + r] = s0[q];
+          o2[(mt * 16 + 4 * g + q) * C2 + 16 + r] = s1[q];
+        }
+      }
+      if (wv == 0) {
+        float ta = bs2a + red[16 * 1024 + 8 * 64 + lane], tb = bs2b + red[17 * 1024 + 8 * 64 + lane];
+        ta += __shfl_xor(ta, 16, 64); ta += __shfl_xor(ta, 32, 64);
+        tb += __shfl_xor(tb, 16, 64); tb += __shfl_xor(tb, 32, 64);
+        if (g == 0) {
+          o2[256 * C2 + r] = ta;
+          o2[256 * C2 + 16 + r] = tb;
+        }
+      }
+    }
+    __syncthreads();
+    mine[0] = acc1[0]; mine[64] = acc1[1]; mine[128] = acc1[2]; mine[192] = acc1[3];
+    red[16 * 1024 + wv * 64 + lane] = bs1;
+    __syncthreads();
+    float* o1 = slab1 + (size_t)blockIdx.x * SLAB1;
+    if (wv < 4) {                                            // K quarters kq = 0 (this wave), 1, 2, 3 (waves + 4, 8, 12)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        f32x4 tot = acc1[mi];
+#pragma unroll
+        for (int kq = 1; kq < 4; ++kq) tot += reinterpret_cast<const f32x4*>(red)[(size_t)(wv + 4 * kq) * 256 + 64 * mi + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o1[((wv * 4 + mi) * 16 + 4 * g + q) * C1 + r] = tot[q];
+      }
+      if (wv == 0) {
+        float t1 = bs1;
+#pragma unroll
+        for (int kq = 1; kq < 4; ++kq) t1 += red[16 * 1024 + 4 * kq * 64 + lane];
+        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+        if (g == 0) o1[256 * C1 + r] = t1;
+      }
+    }
+  }
+  GA3C_STAMP(7);
+}
+
 // ------------------------------------------------------------------ slab reduce (fixed order => reproducible)
 // out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e], for two slab sets in one
 // launch (conv1 and conv2 weight-gradient partials).  Block = 16 waves on the same 64 columns; wave w folds

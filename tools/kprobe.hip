@@ -63,5 +63,36 @@ int main(int argc, char** argv) {
     const char* names[NS] = {"", "issue loads", "wait loads + x->LDS", "W->LDS, zero n1", "barrier 1", "conv1", "barrier 2", "conv2 + stores"};
     for (int k = 1; k < NS; ++k) printf("  %-22s wave0 median %7.0f   slowest-wave median %7.0f ticks\n", names[k], med(seg[k]), med(segmax[k]));
   }
+  // ---- conv_bwd_kernel (f32): one sample per workgroup at B = 128
+  {
+    float *dn2, *dn1, *slab2, *slab1, *pk;
+    CK(hipMalloc(&dn2, (size_t)B * FLAT * 4)); CK(hipMalloc(&dn1, (size_t)B * N1S * 4));
+    CK(hipMalloc(&slab2, (size_t)256 * SLAB2 * 4)); CK(hipMalloc(&slab1, (size_t)512 * SLAB1 * 4)); CK(hipMalloc(&pk, 8192 * 4));
+    CK(hipMemcpy(dn2, hx.data(), (size_t)B * FLAT * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(n1, hx.data() + 12345, (size_t)B * N1S * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(pk, hw.data(), 8192 * 4, hipMemcpyHostToDevice));
+    const size_t cl = CB_LDS_FLOATS * sizeof(float);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
+    const int grid = 2 * B < 256 ? 2 * B : 256;
+    for (int it = 0; it < 4; ++it) {
+      CK(hipMemsetAsync(sb, 0, (size_t)nwg * 16 * 16 * 8, st));
+      hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), cl, st, (const void*)x, n1, dn2, pk, dn1, slab2, slab1, B);
+      CK(hipStreamSynchronize(st));
+    }
+    std::vector<unsigned long long> h((size_t)nwg * 16 * 16);
+    CK(hipMemcpy(h.data(), sb, h.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[8] = {"", "W2 + zeroing + barrier", "stage sample + barrier", "phase 1 (dn1)", "phase 2 (dW2)", "barrier", "phase 3 (dW1, bands)", "fold + slab stores"};
+    std::vector<std::vector<double>> seg(8), segmax(8);
+    for (int gq = 0; gq < grid; ++gq) {
+      std::vector<double> mx(8, 0.0);
+      for (int wv = 0; wv < 16; ++wv) {
+        const unsigned long long* s = &h[((size_t)gq * 16 + wv) * 16];
+        for (int k = 1; k < 8; ++k) { const double d = (double)(s[k] - s[k - 1]); if (wv == 0) seg[k].push_back(d); mx[k] = std::max(mx[k], d); }
+      }
+      for (int k = 1; k < 8; ++k) segmax[k].push_back(mx[k]);
+    }
+    printf("conv_bwd<f32> B=%d\n", B);
+    for (int k = 1; k < 8; ++k) printf("  %-24s wave0 median %7.0f   slowest-wave median %7.0f ticks\n", names[k], med(seg[k]), med(segmax[k]));
+  }
   return 0;
 }
