@@ -348,9 +348,9 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
     // workgroups = partial slabs.  Measured at batch 128 (round 2): 512 / 384 / 256 / 192 / 128 workgroups -> train step
     // 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
-    // (uint8 states: 4-byte loads per pixel, the one-deep prefetch covers less of the longer chain: 512 there)
-    const int cap1 = t.f.x_u8 ? 512 : 256;
-    nch1 = B * 7 < cap1 ? B * 7 : cap1;
+    // ... but uint8 states (4-byte loads per pixel, a longer chain per unit) lose 4 % at 256 (13.6 k vs 14.2 k steps/s), and the
+    // two input formats must cut the units alike to stay bit-identical: 512 for both
+    nch1 = B * 7 < 512 ? B * 7 : 512;
     if (t.f.x_u8)
       hipLaunchKernelGGL(conv1_dw_kernel<true>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
     else
@@ -1696,7 +1696,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       net->d1f_tile = keep;
       CHK(rc);
     } else if (k == "conv1_dw") {
-      TL(conv1_dw_kernel<false>, dim3(B * 7 < 256 ? B * 7 : 256), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
+      TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {
       TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
@@ -1740,7 +1740,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       else if (net->A <= 24) TL((heads_kernel<false, 24>), dim3((B + 3) / 4), h);
       else TL((heads_kernel<false, 64>), dim3((B + 3) / 4), h);
     } else if (k == "slab_reduce") {
-      const int nch1 = B * 7 < 256 ? B * 7 : 256, nch2 = B < 256 ? B : 256;
+      const int nch1 = B * 7 < 512 ? B * 7 : 512, nch2 = B < 256 ? B : 256;
       SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
       SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
       hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2);

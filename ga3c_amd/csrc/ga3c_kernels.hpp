@@ -1540,26 +1540,44 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
 
 // ------------------------------------------------------------------ conv backward, all three gradients of a sample half
 // conv2_dw, conv2_dx and conv1_dw each work sample by sample and hand dn2 -> dn1 through HBM; as three launches they cost
-// three grids of load round trips and two kernel boundaries (6.9 + 6.2 + 9.0 us at batch 128).  Here a workgroup (16 waves)
-// = (sample, half) with the halves of conv_stack_fwd (conv2 pixels 60 | 61; n1 rows 0..10 | 11..20 owned):
-//   phase 1  dn1 rows it owns = the transposed conv of dn2, by parity class (conv2_dx_tiles' arithmetic), ReLU mask
-//            from the n1 image in LDS; the result stays in LDS (and goes to HBM once, for ga3c_net_fetch)
-//   phase 2  dW2 partial over its conv2 pixels: wave = (pair of patch positions, half of the 64 pixel slots): every
-//            (dn2, n1) operand fetch and its pixel -> (row, column) arithmetic feeds 4 MFMAs
-//   phase 3  dW1 partial over its n1 rows in bands of 3 rows: wave = (4 m-tiles, quarter of the band's 64 pixel slots),
-//            the blocking of conv1_dw_kernel; the x bands (16 padded rows, 22.5 KB) arrive by LDS-DMA two bands ahead
-//   (the first version gave every wave one m-tile / one position: one operand pair and one index computation per MFMA made
-//   phases 2 and 3 VALU-bound, 26.8 us against 22.9 us for the three launches; the K-split partial sums of the waves are
-//   folded through LDS once, after the last sample)
-// Everything else the sample needs -- the padded n1 image of the half, the zero-bordered dn2 image, the packed conv12/w
-// of the four parity classes -- is requested at the top with the first two x bands: one memory round trip per sample.
-// Partial dW2 / dW1 (+ bias tails) go to slab2 / slab1 in conv2_dw's / conv1_dw's layout; slab_reduce_kernel is unchanged.
+// three grids of load round trips and two kernel boundaries (6.1 + 5.8 + 8.6 us at batch 128).  Here a workgroup (16 waves)
+// = (sample, half):
+//   phase 1  the dn1 pixels it OWNS = the transposed conv of dn2, by output-pixel parity class (conv2_dx_tiles'
+//            arithmetic), ReLU mask from the n1 image in LDS; the result stays in LDS (and goes to HBM once, for
+//            ga3c_net_fetch).  Ownership is by pixel -- rows 0..9 and row 10 up to column 17 | the rest -- so that every
+//            class of either half fits 4 tiles of 16 pixels: 16 tiles, one per wave (rows 0..10 | 11..20 gave one half 17
+//            tiles, i.e. one wave a second tile of two pixels that everybody waited for).  The ragged class lists live in
+//            an LDS table written once per workgroup.
+//   phase 2  dW2 partial over its conv2 pixels (60 | 61, conv_stack_fwd's cut): wave = (pair of patch positions, half of
+//            the 64 pixel slots): every (dn2, n1) operand fetch and its pixel -> (row, column) arithmetic feeds 4 MFMAs
+//   phase 3  dW1 partial over n1 rows 0..10 | 10..20 in bands of 3 rows (a pixel of row 10 the half does not own is a
+//            zero in its dn1 image): wave = (4 m-tiles, quarter of the band's 64 pixel slots), conv1_dw_kernel's blocking;
+//            the x bands (16 padded rows, 22.5 KB) are requested by LDS-DMA behind the first barrier and two bands ahead
+//   (a first version gave every wave one m-tile / one position: one operand pair and one index computation per MFMA made
+//   phases 2 and 3 VALU-bound, 26.8 us against 22.9 us for the three launches)
+// The K-split partial sums of the waves are folded through LDS once, after the last sample.  Partial dW2 / dW1 (+ bias
+// tails) go to slab2 / slab1 in conv2_dw's / conv1_dw's layout; slab_reduce_kernel is unchanged.
 constexpr int CB_N1IMG = CS_N1ROWS * C2_PW * C1;             // 5376 floats
 constexpr int CB_DN2IMG = 12 * 12 * C2;                      // 4608
 constexpr int CB_W2 = 4 * C2DX_W;                            // 8192
-constexpr int CB_DN1 = 11 * O1 * C1;                         // 3696: owned n1 rows, [row][col][16]
+constexpr int CB_DN1 = 11 * O1 * C1;                         // 3696: n1 rows 0..10 | 10..20, [row][col][16]
 constexpr int CB_XBAND = C1_RIN * C1_PW * 4;                 // 5632 floats per band buffer
-constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + 2 * CB_XBAND;   // 33136 floats = 132,544 B
+constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + 2 * CB_XBAND + 256;   // 33392 floats = 133,568 B
+constexpr int CB_ROW10_CUT = 18;                             // row 10: columns < 18 belong to half 0
+
+// slot m of parity class (py, px) of half h -> (y << 8) | x, or -1
+__device__ __forceinline__ int cb_class_pixel(int h, int py, int px, int m) {
+  const int nx = px ? 10 : 11;
+  if (h == 0) {
+    if (m < 5 * nx) return ((py + 2 * (m / nx)) << 8) | (2 * (m % nx) + px);
+    const int e = m - 5 * nx;
+    return (py == 0 && e < 9) ? ((10 << 8) | (2 * e + px)) : -1;          // row 10: x = px, px + 2, ... <= 17
+  }
+  const int np = py == 0 ? (px ? 1 : 2) : 0;                               // row 10: x = 18, 20 | 19
+  if (m < np) return (10 << 8) | (CB_ROW10_CUT + px + 2 * m);
+  const int e = m - np, ya = e / nx;
+  return ya < 5 ? (((py ? 11 : 12) + 2 * ya) << 8) | (2 * (e % nx) + px) : -1;
+}
 
 template <bool U8>
 __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__ x, const float* __restrict__ n1,
@@ -1571,21 +1589,28 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   float* n1img = cb_lds;                                     // [14][24][16]  n1 rows n1org .. n1org+13, cols -1..22
   float* dnimg = n1img + CB_N1IMG;                           // [12][12][32]  dn2 (i+1, j+1), zero row / column 0
   float* w2l = dnimg + CB_DN2IMG;                            // [4 classes][32][64]
-  float* dn1l = w2l + CB_W2;                                 // [<= 11 rows][21][16]
+  float* dn1l = w2l + CB_W2;                                 // [11 rows][21][16]
   float* xb = dn1l + CB_DN1;                                 // 2 x [16][88][4]
+  int* ptab = reinterpret_cast<int*>(xb + 2 * CB_XBAND);     // [4 classes][64 slots]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   const int h = blockIdx.x & 1, grp = blockIdx.x >> 1, ngrp = gridDim.x >> 1;
   const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;   // conv2 pixels of this half
   const int c2r0 = h ? 5 : 0, n1org = 2 * c2r0 - 1;          // n1 image row 0 holds n1 row n1org
-  const int r0 = h ? 11 : 0, nrows = h ? 10 : 11;            // n1 rows this half owns
-  const int nband = (nrows + C1_HB - 1) / C1_HB;             // 4
-  // ---- once per workgroup: the packed conv12/w, and zeros in every cell no DMA lane will ever write
+  const int r0 = h ? 10 : 0;                                 // first n1 row of its dn1 image; 11 rows, 4 bands
+  constexpr int NROWS = 11, NBAND = 4;
+  // ---- once per workgroup: the packed conv12/w, zeros in the cells no DMA lane will ever write, the class table
   for (int p = wv; p < CB_W2 / 256; p += 16)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w2pk + p * 256 + 4 * lane),
                                      (__attribute__((address_space(3))) void*)(w2l + p * 256), 16, 0, 0);
-  for (int i = threadIdx.x; i < (CB_N1IMG + CB_DN2IMG) / 4; i += 1024) *reinterpret_cast<f32x4*>(&n1img[4 * i]) = zero4();
-  __syncthreads();
-  GA3C_STAMP(1);
+  for (int i = threadIdx.x; i < CB_N1IMG / 4; i += 1024) {
+    const int cell = i >> 2, row = cell / C2_PW, col = cell - row * C2_PW;
+    if (!((unsigned)(n1org + row) < (unsigned)O1 && (unsigned)(col - 1) < (unsigned)O1)) *reinterpret_cast<f32x4*>(&n1img[4 * i]) = zero4();
+  }
+  for (int i = threadIdx.x; i < CB_DN2IMG / 4; i += 1024) {
+    const int cell = i >> 3, pr = cell / 12, pc = cell - pr * 12;
+    if (pr < 1 || pc < 1) *reinterpret_cast<f32x4*>(&dnimg[4 * i]) = zero4();
+  }
+  if (threadIdx.x < 256) ptab[threadIdx.x] = cb_class_pixel(h, threadIdx.x >> 7, (threadIdx.x >> 6) & 1, threadIdx.x & 63);
   f32x4 acc2[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};          // [position of the pair][column half]
   f32x4 acc1[4] = {zero4(), zero4(), zero4(), zero4()};                 // [m-tile of the group]
   float bs2a = 0.f, bs2b = 0.f, bs1 = 0.f;
@@ -1607,7 +1632,8 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
     }
   };
   for (int b = grp; b < B; b += ngrp) {
-    // ---- stage the sample: n1 image (cells of 64 B, 4 lanes each), dn2 image (cells of 128 B, 8 lanes each), x bands 0, 1
+    // ---- stage what phases 1 and 2 read: n1 image (cells of 64 B, 4 lanes each), dn2 image (cells of 128 B, 8 lanes each);
+    // clear the dn1 image (row 10's pixels of the other half stay zero)
     const float* n1b = n1 + (size_t)b * N1S;
     const float* db = dn2 + (size_t)b * FLAT;
     for (int i = threadIdx.x; i < CB_N1IMG / 4; i += 1024) {
@@ -1623,50 +1649,49 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((pr - 1) * O2 + (pc - 1)) * C2 + 4 * (i & 7)),
                                          (__attribute__((address_space(3))) void*)(dnimg + (size_t)(i - lane) * 4), 16, 0, 0);
     }
-    stage_band(b, 0);
+    if (threadIdx.x < CB_DN1 / 4) *reinterpret_cast<f32x4*>(&dn1l[4 * threadIdx.x]) = zero4();
+    __syncthreads();                                         // vmcnt(0) precedes the barrier: the images have landed
+    GA3C_STAMP(1);
+    stage_band(b, 0);                                        // in flight during phases 1 and 2
     stage_band(b, 1);
-    __syncthreads();                                         // vmcnt(0) precedes the barrier: everything has landed
     GA3C_STAMP(2);
-    // ---- phase 1: dn1 rows r0 .. r0+nrows-1 by parity class (16 or 17 tiles of 32 MFMAs)
+    // ---- phase 1: the 16 tiles of its dn1 pixels; wave = (class wv / 4, tile wv % 4)
     {
-      const int nye = h ? 5 : 6, nyo = 5;                    // even / odd rows among the owned ones
-      const int t0 = (nye * 11 + 15) >> 4, t1 = t0 + ((nye * 10 + 15) >> 4), t2 = t1 + ((nyo * 11 + 15) >> 4),
-                t3 = t2 + ((nyo * 10 + 15) >> 4);
-#pragma unroll 1
-      for (int tw = wv; tw < t3; tw += 16) {                 // wave-uniform
-        const int cls = tw < t0 ? 0 : (tw < t1 ? 1 : (tw < t2 ? 2 : 3));
-        const int tile = tw - (cls == 0 ? 0 : (cls == 1 ? t0 : (cls == 2 ? t1 : t2)));
-        const int py = cls >> 1, px = cls & 1, nx = px ? 10 : 11, ccnt = (py ? nyo : nye) * nx;
-        const int yfirst = r0 + ((r0 & 1) == py ? 0 : 1);    // first owned row of this parity
-        const float* wl = w2l + cls * C2DX_W;
-        const int mc = tile * 16 + r;
-        const int mm = mc < ccnt ? mc : 0;
-        const int ya = mm / nx, xa = mm - ya * nx;
-        const int y = yfirst + 2 * ya, xq = 2 * xa + px;
-        const int ih = (y + 1) >> 1, jh = (xq + 1) >> 1;
-        f32x4 a[8];
+      const int cls = wv >> 2, tile = wv & 3;
+      const float* wl = w2l + cls * C2DX_W;
+      const int* tab = ptab + cls * 64 + tile * 16;
+      const int e0 = tab[r];
+      const int e = e0 >= 0 ? e0 : ptab[cls * 64];           // pad slots compute the class's first pixel and store nothing
+      const int y = e >> 8, xq = e & 255;
+      const int ih = (y + 1) >> 1, jh = (xq + 1) >> 1;
+      f32x4 a[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-          a[s] = ld4(dnimg + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
-        f32x4 c0 = zero4(), c1 = zero4();
+      for (int s = 0; s < 8; ++s)
+        a[s] = ld4(dnimg + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
+      f32x4 c0 = zero4(), c1 = zero4();
 #pragma unroll
-        for (int s = 0; s < 8; s += 2)
+      for (int s = 0; s < 8; s += 2) {
+        float wq[8];                                         // (4 waves per SIMD: the other waves cover this fetch)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            c0 = mfma(a[s][t], wl[(s * 4 + t) * 64 + lane], c0);
-            c1 = mfma(a[s + 1][t], wl[((s + 1) * 4 + t) * 64 + lane], c1);
-          }
+        for (int k = 0; k < 8; ++k) wq[k] = wl[(s * 4 + k) * 64 + lane];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int mr = tile * 16 + 4 * g + q;
-          if (mr < ccnt) {
-            const int ya2 = mr / nx, xa2 = mr - ya2 * nx;
-            const int y2 = yfirst + 2 * ya2, x2 = 2 * xa2 + px;
-            const float keep = n1img[((y2 - n1org) * C2_PW + x2 + 1) * C1 + r];
-            const float val = keep > 0.f ? c0[q] + c1[q] : 0.f;
-            dn1l[((y2 - r0) * O1 + x2) * C1 + r] = val;
-            dn1[(size_t)b * N1S + (y2 * O1 + x2) * C1 + r] = val;
-          }
+        for (int k = 0; k < 8; ++k) pin(wq[k]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          c0 = mfma(a[s][t], wq[t], c0);
+          c1 = mfma(a[s + 1][t], wq[4 + t], c1);
+        }
+      }
+      const int4 e4 = *reinterpret_cast<const int4*>(&tab[4 * g]);
+      const int em[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (em[q] >= 0) {
+          const int y2 = em[q] >> 8, x2 = em[q] & 255;
+          const float keep = n1img[((y2 - n1org) * C2_PW + x2 + 1) * C1 + r];
+          const float val = keep > 0.f ? c0[q] + c1[q] : 0.f;
+          dn1l[((y2 - r0) * O1 + x2) * C1 + r] = val;
+          dn1[(size_t)b * N1S + (y2 * O1 + x2) * C1 + r] = val;
         }
       }
     }
@@ -1705,13 +1730,14 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       }
     }
     GA3C_STAMP(4);
-    __syncthreads();                                         // dn1 of the half is complete in LDS
+    __syncthreads();                                         // dn1 of the half is complete in LDS; x bands 0, 1 have landed
     GA3C_STAMP(5);
     // ---- phase 3: dW1 partial, band by band; wave = (m-tiles 4*mg .. 4*mg+3, K quarter kq: pixel slots 16*kq .. 16*kq+15)
-    for (int k = 0; k < nband; ++k) {
+#pragma unroll 1
+    for (int k = 0; k < NBAND; ++k) {
       const float* img = xb + (k & 1) * CB_XBAND;
-      const int brow0 = C1_HB * k;                           // first owned-row index of the band
-      const int bpix = (nrows - brow0 < C1_HB ? nrows - brow0 : C1_HB) * O1;       // 63, or 42 / 21 in the last band
+      const int brow0 = C1_HB * k;                           // first image row of the band
+      const int bpix = (NROWS - brow0 < C1_HB ? NROWS - brow0 : C1_HB) * O1;       // 63; 42 in the last band
       const int mg = wv & 3, kq = wv >> 2;
       float av[4][4], bv[4];
 #pragma unroll
@@ -1741,62 +1767,58 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
         for (int mi = 0; mi < 4; ++mi) acc1[mi] = mfma(av[t][mi], bv[t], acc1[mi]);
       }
       __syncthreads();                                       // band k has been read; band k+1 has landed
-      if (k + 2 < nband) stage_band(b, k + 2);
+      if (k + 2 < NBAND) stage_band(b, k + 2);
     }
     GA3C_STAMP(6);
   }
-  // ---- fold the K-split partial sums of the waves through LDS (fixed order), then write this workgroup's slab pair
+  // ---- fold the K-split partial sums of the waves through LDS (fixed order), then write this workgroup's slab pair:
+  // waves 0-7 the dW2 tiles, waves 8-11 the dW1 tiles, wave 12 the bias sums
   {
-    float* red = cb_lds;                                     // everything staged above is dead now: 16 waves x 1024 floats
+    f32x4* red2 = reinterpret_cast<f32x4*>(cb_lds);          // everything staged above is dead now
+    f32x4* red1 = red2 + 16 * 256;
+    float* redb = cb_lds + 2 * 16 * 1024;                    // bs2a, bs2b of waves 0 and 8; bs1 of waves 0, 4, 8, 12
     __syncthreads();
-    f32x4* mine = reinterpret_cast<f32x4*>(red) + (size_t)wv * 256 + lane;
-    mine[0] = acc2[0][0]; mine[64] = acc2[0][1]; mine[128] = acc2[1][0]; mine[192] = acc2[1][1];
-    red[16 * 1024 + wv * 64 + lane] = bs2a;
-    red[17 * 1024 + wv * 64 + lane] = bs2b;
+    red2[wv * 256 + lane] = acc2[0][0]; red2[wv * 256 + 64 + lane] = acc2[0][1];
+    red2[wv * 256 + 128 + lane] = acc2[1][0]; red2[wv * 256 + 192 + lane] = acc2[1][1];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) red1[wv * 256 + 64 * mi + lane] = acc1[mi];
+    if ((wv & 7) == 0) { redb[(wv >> 3) * 128 + lane] = bs2a; redb[(wv >> 3) * 128 + 64 + lane] = bs2b; }
+    if ((wv & 3) == 0) redb[256 + (wv >> 2) * 64 + lane] = bs1;
     __syncthreads();
     float* o2 = slab2 + (size_t)blockIdx.x * SLAB2;
-    if (wv < 8) {                                            // K halves kh = 0 (this wave) + kh = 1 (wave + 8)
-      const f32x4* other = reinterpret_cast<const f32x4*>(red) + (size_t)(wv + 8) * 256 + lane;
+    float* o1 = slab1 + (size_t)blockIdx.x * SLAB1;
+    if (wv < 8) {                                            // positions 2 wv, 2 wv + 1: K half 0 (wave wv) + K half 1 (wave wv + 8)
 #pragma unroll
       for (int pi = 0; pi < 2; ++pi) {
         const int mt = 2 * wv + pi;                          // patch position = m-tile of conv2_dw's slab layout
-        const f32x4 s0 = acc2[pi][0] + other[128 * pi], s1 = acc2[pi][1] + other[128 * pi + 64];
+        const f32x4 s0 = red2[wv * 256 + 128 * pi + lane] + red2[(wv + 8) * 256 + 128 * pi + lane];
+        const f32x4 s1 = red2[wv * 256 + 128 * pi + 64 + lane] + red2[(wv + 8) * 256 + 128 * pi + 64 + lane];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           o2[(mt * 16 + 4 * g + q) * C2 + r] = s0[q];
           o2[(mt * 16 + 4 * g + q) * C2 + 16 + r] = s1[q];
         }
       }
-      if (wv == 0) {
-        float ta = bs2a + red[16 * 1024 + 8 * 64 + lane], tb = bs2b + red[17 * 1024 + 8 * 64 + lane];
-        ta += __shfl_xor(ta, 16, 64); ta += __shfl_xor(ta, 32, 64);
-        tb += __shfl_xor(tb, 16, 64); tb += __shfl_xor(tb, 32, 64);
-        if (g == 0) {
-          o2[256 * C2 + r] = ta;
-          o2[256 * C2 + 16 + r] = tb;
-        }
-      }
-    }
-    __syncthreads();
-    mine[0] = acc1[0]; mine[64] = acc1[1]; mine[128] = acc1[2]; mine[192] = acc1[3];
-    red[16 * 1024 + wv * 64 + lane] = bs1;
-    __syncthreads();
-    float* o1 = slab1 + (size_t)blockIdx.x * SLAB1;
-    if (wv < 4) {                                            // K quarters kq = 0 (this wave), 1, 2, 3 (waves + 4, 8, 12)
+    } else if (wv < 12) {                                    // m-tiles 4 mg .. 4 mg + 3: K quarters = waves mg, mg + 4, mg + 8, mg + 12
+      const int mg = wv - 8;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        f32x4 tot = acc1[mi];
+        f32x4 tot = red1[mg * 256 + 64 * mi + lane];
 #pragma unroll
-        for (int kq = 1; kq < 4; ++kq) tot += reinterpret_cast<const f32x4*>(red)[(size_t)(wv + 4 * kq) * 256 + 64 * mi + lane];
+        for (int kq = 1; kq < 4; ++kq) tot += red1[(mg + 4 * kq) * 256 + 64 * mi + lane];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o1[((wv * 4 + mi) * 16 + 4 * g + q) * C1 + r] = tot[q];
+        for (int q = 0; q < 4; ++q) o1[((mg * 4 + mi) * 16 + 4 * g + q) * C1 + r] = tot[q];
       }
-      if (wv == 0) {
-        float t1 = bs1;
-#pragma unroll
-        for (int kq = 1; kq < 4; ++kq) t1 += red[16 * 1024 + 4 * kq * 64 + lane];
-        t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
-        if (g == 0) o1[256 * C1 + r] = t1;
+    } else if (wv == 12) {
+      float ta = redb[lane] + redb[128 + lane], tb = redb[64 + lane] + redb[192 + lane];
+      float t1 = (redb[256 + lane] + redb[320 + lane]) + (redb[384 + lane] + redb[448 + lane]);
+      ta += __shfl_xor(ta, 16, 64); ta += __shfl_xor(ta, 32, 64);
+      tb += __shfl_xor(tb, 16, 64); tb += __shfl_xor(tb, 32, 64);
+      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+      if (g == 0) {
+        o2[256 * C2 + r] = ta;
+        o2[256 * C2 + 16 + r] = tb;
+        o1[256 * C1 + r] = t1;
       }
     }
   }
