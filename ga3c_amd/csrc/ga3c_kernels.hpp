@@ -1099,7 +1099,9 @@ __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, cons
 // Workgroup = (sample, class): the sample's dn2 goes to LDS once with a zero row/column for i = -1 / j = -1,
 // the class's 128 x 16 weight sub-matrix goes to LDS in fragment order, and the 7-8 tiles of the class are
 // dealt to the 4 waves.  No atomics, no col buffer; every dn1 element is written exactly once.
-constexpr int C2DX_DN = 12 * 12 * C2;       // padded dn2 image: (i+1, j+1), 4608 floats
+constexpr int C2DX_CELL = C2 + 4;            // floats per pixel cell of the dn2 image in LDS: 36, not 32 -- with 128-byte cells the
+                                            // 16 pixels of a tile hit 2 bank groups with their 16-byte patch reads (8-way conflict)
+constexpr int C2DX_DN = 12 * 12 * C2DX_CELL; // padded dn2 image: (i+1, j+1), 5184 floats
 constexpr int C2DX_W = 32 * 64;             // weight fragments of one class
 
 // the 7-8 tiles of parity class (PY, PX) of one sample, dealt to the 4 waves of a wave group (wg = wave index in the group)
@@ -1128,7 +1130,7 @@ __device__ __forceinline__ void conv2_dx_tiles(const float* __restrict__ dnl, co
     f32x4 a[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-      a[s] = ld4(dnl + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
+      a[s] = ld4(dnl + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2DX_CELL + (s & 1) * 16 + 4 * g);
     f32x4 acc0 = zero4(), acc1 = zero4();
     float wq[2][8];                                      // the 8 weight fragments of an s pair, one pair ahead
     auto load_w = [&](int s, float (&w8)[8]) {
@@ -1168,13 +1170,13 @@ __device__ __forceinline__ void conv2_dx_pair(const float* __restrict__ dn2, con
   for (int i = 0; i < 3; ++i) {
     const int idx = threadIdx.x + 512 * i;                 // float4 index into [12][12][8]
     const int pi = idx >> 3, pr = pi / 12, pc = pi - pr * 12;
-    const bool ok = idx < C2DX_DN / 4 && pr >= 1 && pc >= 1;
+    const bool ok = idx < 12 * 12 * 8 && pr >= 1 && pc >= 1;
     sd[i] = ok ? ld4(db + ((pr - 1) * O2 + (pc - 1)) * C2 + (idx & 7) * 4) : zero4();
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int idx = threadIdx.x + 512 * i;
-    if (idx < C2DX_DN / 4) *reinterpret_cast<f32x4*>(&dnl[idx * 4]) = sd[i];
+    if (idx < 12 * 12 * 8) *reinterpret_cast<f32x4*>(&dnl[(idx >> 3) * C2DX_CELL + (idx & 7) * 4]) = sd[i];
   }
   *reinterpret_cast<f32x4*>(&wl[4 * threadIdx.x]) = sw0;
   *reinterpret_cast<f32x4*>(&wl[C2DX_W + 4 * threadIdx.x]) = sw1;
@@ -1558,11 +1560,11 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
 // The K-split partial sums of the waves are folded through LDS once, after the last sample.  Partial dW2 / dW1 (+ bias
 // tails) go to slab2 / slab1 in conv2_dw's / conv1_dw's layout; slab_reduce_kernel is unchanged.
 constexpr int CB_N1IMG = CS_N1ROWS * C2_PW * C1;             // 5376 floats
-constexpr int CB_DN2IMG = 12 * 12 * C2;                      // 4608
+constexpr int CB_DN2IMG = C2DX_DN;                           // 5184: cells of 36 floats (bank spread, see C2DX_CELL)
 constexpr int CB_W2 = 4 * C2DX_W;                            // 8192
 constexpr int CB_DN1 = 11 * O1 * C1;                         // 3696: n1 rows 0..10 | 10..20, [row][col][16]
 constexpr int CB_XBAND = C1_RIN * C1_PW * 4;                 // 5632 floats per band buffer
-constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + 2 * CB_XBAND + 256;   // 33392 floats = 133,568 B
+constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + 2 * CB_XBAND + 256;   // 33968 floats = 135,872 B
 constexpr int CB_ROW10_CUT = 18;                             // row 10: columns < 18 belong to half 0
 
 // slot m of parity class (py, px) of half h -> (y << 8) | x, or -1
@@ -1606,9 +1608,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
     const int cell = i >> 2, row = cell / C2_PW, col = cell - row * C2_PW;
     if (!((unsigned)(n1org + row) < (unsigned)O1 && (unsigned)(col - 1) < (unsigned)O1)) *reinterpret_cast<f32x4*>(&n1img[4 * i]) = zero4();
   }
-  for (int i = threadIdx.x; i < CB_DN2IMG / 4; i += 1024) {
+  for (int i = threadIdx.x; i < 12 * 12 * 8; i += 1024) {    // only the border cells: the others are written sample by sample
     const int cell = i >> 3, pr = cell / 12, pc = cell - pr * 12;
-    if (pr < 1 || pc < 1) *reinterpret_cast<f32x4*>(&dnimg[4 * i]) = zero4();
+    if (pr < 1 || pc < 1) *reinterpret_cast<f32x4*>(&dnimg[cell * C2DX_CELL + 4 * (i & 7)]) = zero4();
   }
   if (threadIdx.x < 256) ptab[threadIdx.x] = cb_class_pixel(h, threadIdx.x >> 7, (threadIdx.x >> 6) & 1, threadIdx.x & 63);
   f32x4 acc2[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};          // [position of the pair][column half]
@@ -1643,11 +1645,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(n1b + (yy * O1 + xx) * C1 + 4 * (i & 3)),
                                          (__attribute__((address_space(3))) void*)(n1img + (size_t)(i - lane) * 4), 16, 0, 0);
     }
-    for (int i = threadIdx.x; i < CB_DN2IMG / 4; i += 1024) {
-      const int cell = i >> 3, pr = cell / 12, pc = cell - pr * 12;
-      if (pr >= 1 && pc >= 1)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + ((pr - 1) * O2 + (pc - 1)) * C2 + 4 * (i & 7)),
-                                         (__attribute__((address_space(3))) void*)(dnimg + (size_t)(i - lane) * 4), 16, 0, 0);
+    if (threadIdx.x < FLAT / 4) {                            // 968 float4 through registers into the padded cells
+      const int q = threadIdx.x >> 3, i2 = q / O2, j2 = q - i2 * O2;
+      *reinterpret_cast<f32x4*>(&dnimg[((i2 + 1) * 12 + j2 + 1) * C2DX_CELL + 4 * (threadIdx.x & 7)]) = ld4(db + 4 * threadIdx.x);
     }
     if (threadIdx.x < CB_DN1 / 4) *reinterpret_cast<f32x4*>(&dn1l[4 * threadIdx.x]) = zero4();
     __syncthreads();                                         // vmcnt(0) precedes the barrier: the images have landed
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       f32x4 a[8];
 #pragma unroll
       for (int s = 0; s < 8; ++s)
-        a[s] = ld4(dnimg + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2 + (s & 1) * 16 + 4 * g);
+        a[s] = ld4(dnimg + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2DX_CELL + (s & 1) * 16 + 4 * g);
       f32x4 c0 = zero4(), c1 = zero4();
 #pragma unroll
       for (int s = 0; s < 8; s += 2) {
@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
           const float* ap = n1img + ((2 * (i2 - c2r0) + u) * C2_PW + 2 * j2 + v0) * C1 + r;
           a0[t] = ap[0];
           a1[t] = ap[C1];
-          const float* bp = dnimg + (ok ? ((i2 + 1) * 12 + j2 + 1) * C2 : 0);      // cell (0,0) is zero
+          const float* bp = dnimg + (ok ? ((i2 + 1) * 12 + j2 + 1) * C2DX_CELL : 0);      // cell (0,0) is zero
           b0[t] = bp[r];
           b1[t] = bp[16 + r];
         }
