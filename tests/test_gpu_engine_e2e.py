@@ -76,6 +76,10 @@ def test_gather_from_registered_transport_is_bit_identical_to_host_path():
         a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, 10)]
         theta0 = net.get_arena(0)
         net.learning_rate, net.beta = 3e-4, 0.01
+        # Network.log on rows still lying in the transport: the same evaluation as on the copied-out states
+        ev_rows = net.evaluate(None, y, a, offsets=offs)
+        ev_host = net.evaluate(xs, y, a)
+        assert all(np.array_equal(p, q) for p, q in zip(ev_rows, ev_host)) and np.array_equal(net.get_arena(0), theta0)
         net.train_offsets(offs, y, a)
         got = net.get_arena(0)
         net.set_arena(0, theta0)
@@ -84,6 +88,29 @@ def test_gather_from_registered_transport_is_bit_identical_to_host_path():
         assert np.array_equal(got, net.get_arena(0))
         with pytest.raises(RuntimeError):
             net.predict_offsets(np.array([t.nbytes], dtype=np.int64))       # outside the registered segment
+    finally:
+        net.close()
+        t.shutdown()
+        t.close()
+
+
+def test_gather_of_f32_states_from_registered_transport():
+    """STATE_TRANSPORT = 'f32': the slots hold 28,224 floats; the fused conv stack then reads them out of the HIP-registered
+    host segment by LDS-DMA (global_load_lds over PCIe).  Must equal the host-buffer path bit for bit."""
+    import ga3c_amd  # noqa: F401
+    import Transport as tp
+    from NetworkVP import Network
+    t = tp.Transport.create(tp.unique_name("t_zc32"), 24, 6, 4 * 84 * 84 * 4, 4, 6)
+    net = Network("gpu:0", "zc32", 6, (84, 84, 4), max_batch=32, predict_lanes=1)
+    try:
+        net.register_transport(t)
+        rng = np.random.default_rng(13)
+        states = (rng.integers(0, 256, size=(24, 84 * 84 * 4), dtype=np.uint8).astype(np.float32) / np.float32(128) - np.float32(1))
+        t.agent_states.view(np.float32)[:] = states
+        ids = rng.permutation(24)[:17].astype(np.uint32)
+        p1, v1 = net.predict_offsets(t.state_offsets(ids))
+        p2, v2 = net.predict_p_and_v(states[ids].reshape(-1, 84, 84, 4))
+        assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
     finally:
         net.close()
         t.shutdown()

@@ -185,6 +185,12 @@ def test_training_rows_from_the_plane_history(net):
         x = np.stack([states[k] for k in pick])
         y = rng.uniform(-1, 1, len(pick))
         act = np.eye(6, dtype=np.float32)[rng.integers(0, 6, len(pick))]
+        # Network.log on rows named by (agent, plane): the same evaluation as on the states themselves, nothing trained
+        ev_frames = net.evaluate(None, y, act, frames=([a for a, _ in pick], [s for _, s in pick]))
+        ev_states = other.evaluate(x, y, act)
+        assert all(np.array_equal(p, q) for p, q in zip(ev_frames, ev_states))
+        assert np.array_equal(net.get_arena(0), theta)
+        assert net.frames_pushed(int(ids[0])) == steps and net.frames_pushed(1) == 0
         net.train_frames([a for a, _ in pick], [s for _, s in pick], y, act)
         other.train(x, y, act, None, None, 0)
         assert np.array_equal(net.get_arena(0), other.get_arena(0))
