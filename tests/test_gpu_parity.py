@@ -64,7 +64,7 @@ def test_init_matches_oracle_init(nets):
     assert np.array_equal(got, want.astype(np.float32))
 
 
-@pytest.mark.parametrize("num_actions,bsz", [(6, 1), (6, 5), (6, 37), (6, 128), (4, 19), (18, 33)])
+@pytest.mark.parametrize("num_actions,bsz", [(6, 1), (6, 5), (6, 37), (6, 128), (6, 130), (6, 145), (4, 19), (18, 33)])
 def test_forward_matches_oracle(nets, num_actions, bsz):
     net = nets(num_actions)
     _, x, _, _ = _batch(bsz, num_actions, 100 + bsz)
@@ -107,7 +107,7 @@ def test_activations_match_oracle(nets):
         assert np.max(np.abs(got - want)) < TOL, name
 
 
-@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 1, {}), (6, 2, {}), (6, 5, {}), (6, 37, {}), (6, 128, {}), (6, 160, {}),
+@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 1, {}), (6, 2, {}), (6, 5, {}), (6, 37, {}), (6, 128, {}), (6, 131, {}), (6, 160, {}),
                                                    (4, 16, {}), (18, 21, {}), (1, 9, {}), (25, 7, {}), (64, 6, {})])
 def test_gradients_match_oracle(nets, num_actions, bsz, flags):
     net = nets(num_actions)
