@@ -102,6 +102,8 @@ struct TrainLane {
   bool owns_grad = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool exchanged = false;   // the gradients in `grad` have been all-reduced by the backward pass itself (overlapped exchange)
+  bool stepped = false;     // the backward pass has applied RMSProp itself (FusedUpd) into theta[stepped_other]
+  int stepped_other = 0;
 };
 
 // K slices of dense1_fwd.  Its grid is (row blocks) x (2 column halves) x (slices), every slice a partial slab that
@@ -182,6 +184,8 @@ struct ga3c_net {
   hipEvent_t ev_tail_ready = nullptr, ev_head_ready = nullptr, ev_comm_done = nullptr;
   bool comm_overlap = true;            // GA3C_COMM_OVERLAP=0: one blocking all-reduce of the whole arena behind the backward pass
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
+  bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
+                                       // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
   bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
@@ -302,9 +306,12 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
 
 // overlap: the caller will apply the gradients right away (train, not compute_grads): start their all-reduce as soon as
 // each part of the arena is final; returns with the train stream already waiting for the exchange
-int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = false) {
+int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = false, const FusedUpd* fu = nullptr) {
   const int A = net->A;
   const float* th = net->theta[idx];
+  FusedUpd upd;
+  memset(&upd, 0, sizeof upd);
+  if (fu) upd = *fu;
   hipStream_t st = t.st;
   float* g = t.grad;
   HeadBwdArgs hb;
@@ -314,6 +321,7 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     Dense1TileArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
     d.hb = hb;
+    d.upd = upd;
     d.role_blocks = A + 2 < 14 ? A + 2 : 14;       // 242 tiles + the roles stay within one round of workgroups on 256 CUs
     hipLaunchKernelGGL(dense1_bwd_tile_kernel, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
   } else {
@@ -357,9 +365,9 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
       hipLaunchKernelGGL(conv1_dw_kernel<false>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.x, t.dn1, t.slab1, B * 7);
   }
   {
-    SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
-    SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2);
+    SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64, OFF_W1, OFF_B1};
+    SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64, OFF_W2, OFF_B2};
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2, upd);
   }
   HIPCHK(hipGetLastError());
   if (overlap) {
@@ -491,19 +499,81 @@ int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* o
 }
 
 // gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller)
-int train_grads(ga3c_net* net, TrainLane& t, int B, float beta, bool will_apply = false) {
-  int idx;
-  {
+// Before the weight buffer `other` = 1 - latest is overwritten: predictions move over to `latest` (they may have to wait for
+// the step that wrote it), and the train stream waits for every prediction lane that has read `other` since it was last
+// written.  Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only when a
+// lane has really touched the buffer.
+int claim_other_buffer(ga3c_net* net, TrainLane& t, int* idx_out, int* other_out) {
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  const int idx = net->latest, other = 1 - idx;
+  if (net->cur.load() != idx) {
+    // no prediction has moved over to the previous step's weights yet, and this step is about to overwrite the buffer
+    // predictions still read: move them now; they wait for that step only if it is still in flight
+    // (without an event -- no predictions were around -- the next prediction marks the train stream itself and waits)
+    net->must_wait[idx] = net->event_valid[idx] ? hipEventQuery(net->theta_ready[idx]) != hipSuccess : true;
+    net->cur.store(idx);
+  }
+  for (Lane* L : net->lanes) {
+    if (L->dirty[other]) {
+      HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
+      L->dirty[other] = false;
+    }
+  }
+  *idx_out = idx;
+  *other_out = other;
+  return GA3C_OK;
+}
+
+// the optimizer step that wrote theta[other] has been enqueued on the train stream
+int publish_other_buffer(ga3c_net* net, TrainLane& t, int other) {
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  const uint64_t seq = net->pred_seq.load();
+  net->event_valid[other] = seq != net->pred_seen;   // predictions are arriving: give them an event to poll
+  net->pred_seen = seq;
+  if (net->event_valid[other]) HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
+  net->latest = other;
+  net->step.fetch_add(1);
+  return GA3C_OK;
+}
+
+// gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller).  will_apply: the
+// caller steps the optimizer right away (train, not compute_grads).  Then (a) with a communicator the exchange is started
+// inside the backward pass, and (b) without one, and without clipping, the backward kernels apply RMSProp themselves to
+// the elements whose gradient they complete (FusedUpd): train_apply then has nothing left to launch.
+int train_grads(ga3c_net* net, TrainLane& t, int B, float beta, bool will_apply = false, float lr = 0.f) {
+  const bool fuse = will_apply && net->fused_update && !net->comm && !(net->cfg.flags & GA3C_FLAG_GRAD_CLIP) &&
+                    B <= net->d1b_tile_max;
+  int idx, other;
+  if (fuse && !net->hogwild) {
+    CHK(claim_other_buffer(net, t, &idx, &other));
+  } else {
     std::shared_lock<std::shared_mutex> lk(net->wmu);
-    idx = net->latest;   // the newest weights: written by this same stream (synchronous mode) or in place (Hogwild)
+    idx = other = net->latest;   // the newest weights: written by this same stream (synchronous mode) or in place (Hogwild)
   }
   CHK(launch_forward(net, t.f, idx, B, t.st, true, &t, beta));
   t.exchanged = will_apply && net->comm && net->comm_overlap && !net->hogwild && &t == &net->tr;
-  CHK(launch_backward(net, t, idx, B, t.exchanged));
+  FusedUpd fu;
+  memset(&fu, 0, sizeof fu);
+  if (fuse) {
+    fu.tin = net->theta[idx]; fu.tout = net->theta[other]; fu.ms = net->ms; fu.mom = net->mom; fu.pk = net->theta_pk[other];
+    fu.lr = lr; fu.omr = 1.0f - net->cfg.rmsprop_decay; fu.mu = net->cfg.rmsprop_momentum; fu.eps = net->cfg.rmsprop_epsilon;
+    fu.on = 1;
+  }
+  CHK(launch_backward(net, t, idx, B, t.exchanged, fuse ? &fu : nullptr));
+  t.stepped = fuse;
+  t.stepped_other = other;
   return GA3C_OK;
 }
 
 int train_apply(ga3c_net* net, TrainLane& t, float lr) {
+  if (t.stepped) {           // the backward kernels have applied the step (train_grads, FusedUpd)
+    t.stepped = false;
+    if (net->hogwild) {
+      net->step.fetch_add(1);
+      return GA3C_OK;
+    }
+    return publish_other_buffer(net, t, t.stepped_other);
+  }
   if (net->hogwild) {
     // The reference's NT trainer threads run sess.run(train_op) concurrently on shared variables without locking
     // (Server.py:132-134, TF use_locking=False): every lane updates theta / ms in place from its own stream; reads by
@@ -516,31 +586,10 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
   if (net->comm && !t.exchanged)       // (train_grads has already exchanged the gradients when it knew a step would follow)
     NCCLCHK(ncclAllReduce(t.grad, t.grad, (size_t)net->n, ncclFloat, ncclSum, net->comm, t.st));
   t.exchanged = false;
-  std::unique_lock<std::shared_mutex> lk(net->wmu);
-  const int idx = net->latest, other = 1 - idx;
-  if (net->cur.load() != idx) {
-    // no prediction has moved over to the previous step's weights yet, and this step is about to overwrite the buffer
-    // predictions still read: move them now; they wait for that step only if it is still in flight
-    // (without an event -- no predictions were around -- the next prediction marks the train stream itself and waits)
-    net->must_wait[idx] = net->event_valid[idx] ? hipEventQuery(net->theta_ready[idx]) != hipSuccess : true;
-    net->cur.store(idx);
-  }
-  // Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only
-  // when a prediction lane has really touched the buffer about to be overwritten.
-  for (Lane* L : net->lanes) {
-    if (L->dirty[other]) {
-      HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
-      L->dirty[other] = false;
-    }
-  }
+  int idx, other;
+  CHK(claim_other_buffer(net, t, &idx, &other));
   CHK(launch_rmsprop(net, t.grad, t.scales, net->theta[idx], net->theta[other], net->theta_pk[other], lr, t.st));
-  const uint64_t seq = net->pred_seq.load();
-  net->event_valid[other] = seq != net->pred_seen;   // predictions are arriving: give them an event to poll
-  net->pred_seen = seq;
-  if (net->event_valid[other]) HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
-  net->latest = other;
-  net->step.fetch_add(1);
-  return GA3C_OK;
+  return publish_other_buffer(net, t, other);
 }
 
 int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, const float* y_r, const float* a, int B) {
@@ -861,6 +910,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
   for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CB_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) {
@@ -1100,7 +1150,7 @@ int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float*
   TrainLane* t = take_train_lane(net);
   std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
   CHK(stage_train_inputs(net, *t, x, false, y_r, a, batch));
-  CHK(train_grads(net, *t, batch, beta, true));
+  CHK(train_grads(net, *t, batch, beta, true, learning_rate));
   CHK(train_apply(net, *t, learning_rate));
   return read_losses(net, *t, losses);
 }
@@ -1112,7 +1162,7 @@ int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const f
   TrainLane* t = take_train_lane(net);
   std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
   CHK(stage_train_inputs(net, *t, x, true, y_r, a, batch));
-  CHK(train_grads(net, *t, batch, beta, true));
+  CHK(train_grads(net, *t, batch, beta, true, learning_rate));
   CHK(train_apply(net, *t, learning_rate));
   return read_losses(net, *t, losses);
 }
@@ -1186,7 +1236,7 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   TrainLane& t = *tp;
   CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.f, t.st));
   CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta, true));
+  CHK(train_grads(net, t, batch, beta, true, learning_rate));
   CHK(train_apply(net, t, learning_rate));
   return read_losses(net, t, losses);
 }
@@ -1424,7 +1474,7 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
   std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
   TrainLane& t = *tp;
   CHK(stage_history_rows(net, t, agents, seqs, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta, true));
+  CHK(train_grads(net, t, batch, beta, true, learning_rate));
   CHK(train_apply(net, t, learning_rate));
   return read_losses(net, t, losses);
 }
@@ -1550,7 +1600,7 @@ int ga3c_net_train_resident(ga3c_net* net, int32_t batch, float learning_rate, f
   if (!net) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   std::lock_guard<std::mutex> tl(net->tr.mu);
-  CHK(train_grads(net, net->tr, batch, beta, true));
+  CHK(train_grads(net, net->tr, batch, beta, true, learning_rate));
   return train_apply(net, net->tr, learning_rate);
 }
 
@@ -1572,7 +1622,7 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
     if (mode == 0) {
       CHK(resident_predict_locked(net, batch));
     } else {
-      CHK(train_grads(net, net->tr, batch, beta, true));
+      CHK(train_grads(net, net->tr, batch, beta, true, learning_rate));
       CHK(train_apply(net, net->tr, learning_rate));
     }
   }
@@ -1652,7 +1702,7 @@ int ga3c_net_time_train_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32
   const auto h0 = std::chrono::steady_clock::now();
   for (int i = 0; i < iters; ++i) {
     TrainLane& t = (i % nlanes) == 0 ? net->tr : *net->xtr[(i % nlanes) - 1];
-    CHK(train_grads(net, t, batch, beta));
+    CHK(train_grads(net, t, batch, beta, true, learning_rate));
     CHK(train_apply(net, t, learning_rate));
   }
   CHK(sync_all(net));
@@ -1726,6 +1776,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.hb.B = B; d.hb.A = net->A; d.hb.d1 = t.f.d1; d.hb.dz = t.dz; d.hb.dv = t.dv; d.hb.lossrow = t.lossrow;
       d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
       d.role_blocks = net->A + 2 < 14 ? net->A + 2 : 14;
+      memset(&d.upd, 0, sizeof d.upd);
       hipExtLaunchKernelGGL(dense1_bwd_tile_kernel, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, d);
     } else if (k == "heads") {
@@ -1741,9 +1792,11 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       else TL((heads_kernel<false, 64>), dim3((B + 3) / 4), h);
     } else if (k == "slab_reduce") {
       const int nch1 = B * 7 < 512 ? B * 7 : 512, nch2 = B < 256 ? B : 256;
-      SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64};
-      SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64};
-      hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2);
+      SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64, OFF_W1, OFF_B1};
+      SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64, OFF_W2, OFF_B2};
+      FusedUpd noupd;
+      memset(&noupd, 0, sizeof noupd);
+      hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2, noupd);
     } else if (k == "rmsprop") {
       const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
       TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->latest], net->ms, net->mom, t.grad, net->n,

@@ -64,6 +64,27 @@ __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// RMSProp applied by the kernel that PRODUCES a gradient element (single-GPU train steps without clipping): the optimizer's
+// own launch, and its pass over the 4 MB dense1/w gradient, disappear.  Same arithmetic as rmsprop_one below
+// (TF-1.x ApplyRMSProp: ms += (g*g - ms)*(1-rho); mom = mom*mu + g*lr/sqrt(eps+ms); theta_out = theta_in - mom).
+struct FusedUpd {
+  const float* tin; float* tout; float* ms; float* mom; float* pk;   // pk: packed copies (dense1/w, conv12/w) of tout
+  float lr, omr, mu, eps; int on;
+};
+__device__ __forceinline__ float fused_rmsprop(const FusedUpd& u, int64_t i, float g) {
+  float m = u.ms[i];
+  m += (g * g - m) * u.omr;
+  u.ms[i] = m;
+  float step = (g * u.lr) / sqrtf(u.eps + m);
+  if (u.mu != 0.f) {
+    step = u.mom[i] * u.mu + step;
+    u.mom[i] = step;
+  }
+  const float tn = u.tin[i] - step;
+  u.tout[i] = tn;
+  return tn;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1220,7 +1241,7 @@ constexpr int D1B_LDS_FLOATS = D1B_ROWS * D1B_DS + D1B_COLS * D1B_DS + D1B_COLS 
 constexpr int D1B_TILES = FLAT / D1B_COLS;       // 242
 
 // head weight gradients / loss sums for a 1024-thread block (same arithmetic order as heads_bwd_role up to the fold width)
-__device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int role, float* lds) {
+__device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int role, float* lds, const FusedUpd& u) {
   f32x4* sacc = reinterpret_cast<f32x4*>(lds);            // [16][64]
   float* sh = lds + 16 * 64 * 4;                           // [16]
   const int k = threadIdx.x, kq = k & 63, bg = k >> 6;
@@ -1264,10 +1285,12 @@ __device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int ro
       for (int q = 0; q < 4; ++q) {
         if (isv) h.g_wv[4 * kq + q] = tot[q];
         else h.g_wp[(size_t)(4 * kq + q) * h.A + o] = tot[q];
+        if (u.on) fused_rmsprop(u, isv ? OFF_WV + 4 * kq + q : OFF_WP + (int64_t)(4 * kq + q) * h.A + o, tot[q]);
       }
     }
     if (k == 0) {
       if (isv) h.g_bv[0] = bsum; else h.g_bp[o] = bsum;
+      if (u.on) fused_rmsprop(u, isv ? OFF_BV : off_bp(h.A) + o, bsum);
     }
   } else {
     for (int c = 0; c < 3; ++c) {
@@ -1282,12 +1305,13 @@ __device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int ro
 struct Dense1TileArgs {
   const float* n2; const float* dd1; const float* wd; float* g_wd; float* g_bd; float* dn2; int B;
   HeadBwdArgs hb; int role_blocks;
+  FusedUpd upd;      // on: dense1/w, dense1/b and the head parameters are stepped here (see FusedUpd)
 };
 
 __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float d1b_lds[];
   if ((int)blockIdx.x >= D1B_TILES) {                       // block-uniform: the head roles, dealt round-robin
-    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide(a.hb, role, d1b_lds);
+    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide(a.hb, role, d1b_lds, a.upd);
     return;
   }
   float* dds = d1b_lds;                                     // [128][260]  dd1 rows of the chunk
@@ -1392,21 +1416,60 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
       }
     }
   }
+  // ---- epilogue: the 16 x 256 dWd tile goes through LDS so that gradient, ms and weights move as whole 1 KB rows
+  // (16 bytes per lane) -- the accumulator layout would touch them in 64-byte pieces -- and all 16 waves take part
+  __syncthreads();                                             // every wave is done with the staged operands
+  float* gt = d1b_lds;                                         // [16][256]
   if (wv < 8) {
     const int n0 = wv * 32;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        a.g_wd[(size_t)(k0 + 4 * g + q) * HID + n0 + ni * 16 + r] = accw[ni][0][q] + accw[ni][1][q];
+      for (int q = 0; q < 4; ++q) gt[(4 * g + q) * HID + n0 + ni * 16 + r] = accw[ni][0][q] + accw[ni][1][q];
     if (blockIdx.x == 0) {
       bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
       bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
       if (g == 0) {
         a.g_bd[n0 + r] = bs0;
         a.g_bd[n0 + 16 + r] = bs1;
+        if (a.upd.on) {
+          fused_rmsprop(a.upd, OFF_BD + n0 + r, bs0);
+          fused_rmsprop(a.upd, OFF_BD + n0 + 16 + r, bs1);
+        }
       }
     }
+  }
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 6, c4 = (threadIdx.x & 63) * 4;
+    const int64_t idx = (int64_t)(k0 + row) * HID + c4;
+    const f32x4 gv = ld4(gt + row * HID + c4);
+    *reinterpret_cast<f32x4*>(a.g_wd + idx) = gv;
+    if (a.upd.on) {
+      const FusedUpd& u = a.upd;
+      f32x4 m = ld4(u.ms + OFF_WD + idx);
+      const f32x4 th = ld4(u.tin + OFF_WD + idx);
+      f32x4 mo = u.mu != 0.f ? ld4(u.mom + OFF_WD + idx) : zero4();
+      f32x4 tn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        m[e] += (gv[e] * gv[e] - m[e]) * u.omr;
+        float step = (gv[e] * u.lr) / sqrtf(u.eps + m[e]);
+        if (u.mu != 0.f) { step = mo[e] * u.mu + step; mo[e] = step; }
+        tn[e] = th[e] - step;
+      }
+      *reinterpret_cast<f32x4*>(u.ms + OFF_WD + idx) = m;
+      if (u.mu != 0.f) *reinterpret_cast<f32x4*>(u.mom + OFF_WD + idx) = mo;
+      *reinterpret_cast<f32x4*>(u.tout + OFF_WD + idx) = tn;
+      *reinterpret_cast<f32x4*>(gt + row * HID + c4) = tn;       // for the fragment-ordered copy below
+    }
+  }
+  if (a.upd.on) {
+    __syncthreads();
+    // the fragment-ordered copy dense1_fwd reads: rows 4 kq .. 4 kq + 3 of column n are 16 contiguous bytes there
+    const int n = threadIdx.x & 255, kq = threadIdx.x >> 8;
+    const f32x4 v = {gt[(4 * kq) * HID + n], gt[(4 * kq + 1) * HID + n], gt[(4 * kq + 2) * HID + n], gt[(4 * kq + 3) * HID + n]};
+    *reinterpret_cast<f32x4*>(a.upd.pk + ((size_t)blockIdx.x * HID + n) * 16 + 4 * kq) = v;
   }
 }
 
@@ -1829,9 +1892,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
 // out_w[e] (e < nw) and out_b[e-nw] (nw <= e < stride) = sum_c part[c*stride + e], for two slab sets in one
 // launch (conv1 and conv2 weight-gradient partials).  Block = 16 waves on the same 64 columns; wave w folds
 // chunks w, w+16, ... (8 loads in flight), then wave 0 adds the 16 partial rows in order.
-struct SlabSet { const float* part; int nchunks; int stride; int nw; float* out_w; float* out_b; int nblocks; };
+struct SlabSet { const float* part; int nchunks; int stride; int nw; float* out_w; float* out_b; int nblocks; int64_t off_w; int64_t off_b; };
 
-__global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s1) {
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s1, FusedUpd u) {
   __shared__ float sh[16][64];
   const bool first = (int)blockIdx.x < s0.nblocks;
   const SlabSet& ss = first ? s0 : s1;
@@ -1857,6 +1920,11 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s
 #pragma unroll
     for (int i = 0; i < 16; ++i) tot += sh[i][lane];
     if (e < ss.nw) ss.out_w[e] = tot; else ss.out_b[e - ss.nw] = tot;
+    if (u.on) {   // the conv parameters are stepped where their gradient is completed (off_w / off_b: arena offsets)
+      const int64_t i = e < ss.nw ? ss.off_w + e : ss.off_b + (e - ss.nw);
+      const float tn = fused_rmsprop(u, i, tot);
+      if (i >= OFF_W2 && i < OFF_B2) u.pk[PK_W2DX + w2dx_packed_index((int)(i - OFF_W2))] = tn;
+    }
   }
 }
 
