@@ -26,7 +26,7 @@ def traffic_key(k):
     tag = ''
     if base in ('conv_stack_fwd',) and len(args) >= 2:
         tag = ('_train' if args[0] == 'true' else '') + ('_u8' if args[1] == 'true' else '')
-    elif base in ('conv1_dw', 'conv1_fwd') and args:
+    elif base in ('conv1_dw', 'conv1_fwd', 'conv_bwd') and args:
         tag = '_u8' if args[0] == 'true' else ''
     elif base == 'heads' and args:
         tag = '_train' if args[0] == 'true' else ''
@@ -49,6 +49,7 @@ ALGORITHMIC_MB = {
     "dense1_dw_kernel": N2 + 0.13 + WD, "dense1_dx_kernel": 0.13 + WD + N2 + N2,
     "conv2_dw_kernel": N1 + N2 + 128 * 8224 * 4 / MB, "conv2_dx_kernel": N2 + N1 + N1,
     "conv1_dw_kernel<false>": X_F32 + N1 + 256 * 4112 * 4 / MB, "conv1_dw_kernel<true>": X_U8 + N1 + 256 * 4112 * 4 / MB,
+    "conv_bwd_kernel<false>": X_F32 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB, "conv_bwd_kernel<true>": X_U8 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB,
     "slab_reduce_kernel": (256 * 4112 + 128 * 8224) * 4 / MB, "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
     "pack_wd_kernel": 2 * WD, "frame_frontend_kernel<3>": 256 * 157248 / MB,
 }
