@@ -334,18 +334,23 @@ def main():
         flop_launch = (FLOP_CONV1_PER_SAMPLE + FLOP_CONV2_PER_SAMPLE) * B
         t_conv = kernels["conv_stack_fwd"] * 1e-6
         achieved = flop_launch / t_conv / 1e12
-        traffic, traffic_commit, traffic_src = None, None, None
+        traffic, traffic_commit, traffic_src, prof_us = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj.get("conv_stack_fwd_B%d" % B)
             traffic_commit, traffic_src = tj.get("commit"), tj.get("source")
+            prof_us = tj.get("conv_stack_fwd_B%d_rocprof_avg_us" % B)
         out["roofline"] = {"kernel": "conv_stack_fwd_kernel<false>", "bound": "mfma", "achieved": achieved,
                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_commit": traffic_commit, "traffic_source": traffic_src,
                            "avg_launch_us": kernels["conv_stack_fwd"], "algorithmic_flop_per_launch": flop_launch,
                            "algorithmic_bytes_per_launch": B * (84 * 84 * 4 * 4 + 11 * 11 * 32 * 4) + 4 * (4112 + 8224)}
+        if prof_us:      # rocprofv3's begin-to-end time of each dispatch in the committed profile (includes the dispatch ramp that
+            #              back-to-back launches overlap with the previous kernel's drain; the live figure above is launch-to-launch)
+            out["roofline"]["profile_avg_launch_us"] = prof_us
+            out["roofline"]["profile_frac"] = flop_launch / (prof_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS
         out["kernel_us"] = kernels
         flop = FLOP_PER_PREDICTION.get(A, 7_581_184)
         out["end_to_end_mfma_frac"] = out["value"] * flop / (world * MFMA_F32_PEAK_TFLOPS * 1e12)

@@ -35,6 +35,10 @@ except OSError:
     old = {}
 keep = {k: v for k, v in old.items() if k.startswith("frame_frontend")}      # collected by tools/frontend_bench.py passes
 merged = dict(keep, **new)
+import csv
+for r in csv.DictReader(open("profiles/%s_kernel_stats_B128_single_lane.csv" % tag)):
+    if "conv_stack_fwd_kernel<false, false>" in r["Name"]:
+        merged["conv_stack_fwd_B128_rocprof_avg_us"] = float(r["AverageNs"]) / 1e3     # begin-to-end of each dispatch
 merged["commit"] = commit
 merged["source"] = "profiles/%s_pmc_B128.md" % tag
 merged["frontend_source"] = old.get("frontend_source", "profiles/r01_l_frontend_pmc.md (round 1; the front-end kernel is unchanged since)")
