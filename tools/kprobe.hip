@@ -60,8 +60,21 @@ int main(int argc, char** argv) {
     std::sort(start.begin(), start.end());
     printf("conv_stack_fwd<%s> B=%d: kernel span %llu ticks; WG start spread: median %.0f last %.0f; WG span median %.0f\n",
            u8 ? "u8" : "f32", B, t1 - t0, med(start), start.back(), med(wgspan));
-    const char* names[NS] = {"", "issue loads", "wait loads + x->LDS", "W->LDS, zero n1", "barrier 1", "conv1", "barrier 2", "conv2 + stores"};
-    for (int k = 1; k < NS; ++k) printf("  %-22s wave0 median %7.0f   slowest-wave median %7.0f ticks\n", names[k], med(seg[k]), med(segmax[k]));
+    const char* names[NS] = {"", "issue loads, zero n1", "W1 (u8: x too) -> LDS", "-", "barrier 1", "conv1 tile, W2 -> LDS", "barrier 2", "conv2 + stores"};
+    for (int k = 1; k < NS; ++k) printf("  %-36s wave0 median %7.0f   slowest-wave median %7.0f ticks\n", names[k], med(seg[k]), med(segmax[k]));
+    for (int wsel : {0, 8}) {                              // cumulative, from the workgroup's first stamp: an early and a late wave
+      printf("  wave %d, ticks since the workgroup started:", wsel);
+      for (int k = 0; k < NS; ++k) {
+        std::vector<double> c;
+        for (int g = 0; g < nwg; ++g) {
+          unsigned long long w0 = ~0ull;
+          for (int wv = 0; wv < 16; ++wv) w0 = std::min(w0, h[((size_t)g * 16 + wv) * 16]);
+          c.push_back((double)(h[((size_t)g * 16 + wsel) * 16 + k] - w0));
+        }
+        printf(" [%d] %.0f", k, med(c));
+      }
+      printf("\n");
+    }
   }
   // ---- conv_bwd_kernel (f32): one sample per workgroup at B = 128
   {
