@@ -708,11 +708,9 @@ struct HeadArgs {
   float beta, log_eps, min_policy; int log_softmax;
 };
 
-template <bool TRAIN, int AMAX>
-__global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= h.B) return;   // wave-uniform
+// NR rows per wave (rows[j] < 0: none; wave-uniform): every load of every row is requested before the first reduction
+template <bool TRAIN, int AMAX, int NR>
+__device__ __forceinline__ void heads_rows(const HeadArgs& h, const int (&rows)[NR], int lane) {
   // this lane's 4 hidden units x A policy weights are 4*A contiguous floats: issue every load up front
   float wreg[4][AMAX];
   const float* wp = h.wp + (size_t)(4 * lane) * h.A;
@@ -721,95 +719,181 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
 #pragma unroll
     for (int o = 0; o < AMAX; ++o) wreg[q][o] = o < h.A ? wp[q * h.A + o] : 0.f;
   const f32x4 wv4 = ld4(h.wv + 4 * lane);
-  f32x4 d = ld4(h.bd + 4 * lane);
+  const f32x4 bd4 = ld4(h.bd + 4 * lane);
   // everything the tail needs is requested now, with the slab loads, not after the reductions (one round trip, not three)
   const bool mine = lane < h.A;
   const float bp_mine = mine ? h.bp[lane] : 0.f;
   const float bv0 = h.bv[0];
-  float y = 0.f, a = 0.f;
-  if (TRAIN) {
-    y = h.y_r[b];
-    a = mine ? h.act[(size_t)b * h.A + lane] : 0.f;
-  }
-  const float* pp = h.part + (size_t)b * HID + 4 * lane;
+  float y[NR], a[NR];
+  f32x4 dr[NR];
   const size_t kstride = (size_t)h.B * HID;
-  {   // dense_ks() picks at most 22 slices: all of them in flight at once, summed in slice order
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    y[j] = a[j] = 0.f;
+    dr[j] = bd4;
+    if (rows[j] < 0) continue;
+    const int b = rows[j];
+    if (TRAIN) {
+      y[j] = h.y_r[b];
+      a[j] = mine ? h.act[(size_t)b * h.A + lane] : 0.f;
+    }
+    const float* pp = h.part + (size_t)b * HID + 4 * lane;
+    // dense_ks() picks at most 22 slices: all of them in flight at once, summed in slice order
     f32x4 t[22];
 #pragma unroll
     for (int i = 0; i < 22; ++i) t[i] = i < h.ks ? ld4(pp + (size_t)i * kstride) : zero4();
 #pragma unroll
-    for (int i = 0; i < 22; ++i) d += t[i];
+    for (int i = 0; i < 22; ++i) dr[j] += t[i];
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) d[q] = fmaxf(d[q], 0.f);
-  *reinterpret_cast<f32x4*>(h.d1 + (size_t)b * HID + 4 * lane) = d;
+  for (int j = 0; j < NR; ++j) {
+    if (rows[j] < 0) continue;
+    const int b = rows[j];
+    f32x4 d = dr[j];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] = fmaxf(d[q], 0.f);
+    *reinterpret_cast<f32x4*>(h.d1 + (size_t)b * HID + 4 * lane) = d;
 
-  const float v = wave_sum(d[0] * wv4[0] + d[1] * wv4[1] + d[2] * wv4[2] + d[3] * wv4[3]) + bv0;
-  float zpart[AMAX];
+    const float v = wave_sum(d[0] * wv4[0] + d[1] * wv4[1] + d[2] * wv4[2] + d[3] * wv4[3]) + bv0;
+    float zpart[AMAX];
 #pragma unroll
-  for (int o = 0; o < AMAX; ++o) zpart[o] = d[0] * wreg[0][o] + d[1] * wreg[1][o] + d[2] * wreg[2][o] + d[3] * wreg[3][o];
+    for (int o = 0; o < AMAX; ++o) zpart[o] = d[0] * wreg[0][o] + d[1] * wreg[1][o] + d[2] * wreg[2][o] + d[3] * wreg[3][o];
 #pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1)
+    for (int sh = 32; sh > 0; sh >>= 1)
 #pragma unroll
-    for (int o = 0; o < AMAX; ++o) zpart[o] += __shfl_xor(zpart[o], sh, 64);
-  float zmine = -INFINITY;
+      for (int o = 0; o < AMAX; ++o) zpart[o] += __shfl_xor(zpart[o], sh, 64);
+    float zmine = -INFINITY;
 #pragma unroll
-  for (int o = 0; o < AMAX; ++o)
-    if (lane == o && o < h.A) zmine = zpart[o] + bp_mine;
-  const float zmax = wave_max(zmine);
-  const float e = mine ? expf(zmine - zmax) : 0.f;
-  const float esum = wave_sum(e);
-  const float s = e / esum;
-  const float denom = 1.0f + h.min_policy * (float)h.A;
-  const float p = h.log_softmax ? s : (s + h.min_policy) / denom;
-  if (mine) {
-    h.z[(size_t)b * h.A + lane] = zmine;
-    h.p[(size_t)b * h.A + lane] = p;
-  }
-  if (lane == 0) h.v[b] = v;
-  if (TRAIN) {
-    const float adv = y - v;
-    float dz, c1, c2;
-    if (h.log_softmax) {
-      const float ls = mine ? (zmine - zmax) - logf(esum) : 0.f;
-      const float lsel = wave_sum(ls * a);
-      const float ent = wave_sum(mine ? s * ls : 0.f);
-      const float asum = wave_sum(a);
-      c1 = lsel * adv;
-      c2 = -h.beta * ent;
-      dz = -adv * (a - s * asum) + h.beta * s * (ls - ent);
-    } else {
-      const float sel = wave_sum(mine ? p * a : 0.f);
-      const float logp = logf(fmaxf(p, h.log_eps));
-      c1 = logf(fmaxf(sel, h.log_eps)) * adv;
-      c2 = -h.beta * wave_sum(mine ? logp * p : 0.f);
-      const float gsel = sel >= h.log_eps ? 1.0f / sel : 0.f;
-      const float gp = -(adv * gsel) * a + h.beta * (logp + (p >= h.log_eps ? 1.0f : 0.f));
-      const float gs = mine ? gp / denom : 0.f;
-      const float dot = wave_sum(gs * s);
-      dz = s * (gs - dot);
+    for (int o = 0; o < AMAX; ++o)
+      if (lane == o && o < h.A) zmine = zpart[o] + bp_mine;
+    const float zmax = wave_max(zmine);
+    const float e = mine ? expf(zmine - zmax) : 0.f;
+    const float esum = wave_sum(e);
+    const float s = e / esum;
+    const float denom = 1.0f + h.min_policy * (float)h.A;
+    const float p = h.log_softmax ? s : (s + h.min_policy) / denom;
+    if (mine) {
+      h.z[(size_t)b * h.A + lane] = zmine;
+      h.p[(size_t)b * h.A + lane] = p;
     }
-    if (mine) h.dz[(size_t)b * h.A + lane] = dz;
-    {
-      const float dvv = v - y;
-      f32x4 dd = {dvv * wv4[0], dvv * wv4[1], dvv * wv4[2], dvv * wv4[3]};
-#pragma unroll
-      for (int o = 0; o < AMAX; ++o) {
-        const float dzo = __shfl(dz, o, 64);          // 0 for lanes >= A
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dd[q] += dzo * wreg[q][o];
+    if (lane == 0) h.v[b] = v;
+    if (TRAIN) {
+      const float yy = y[j], aa = a[j];
+      const float adv = yy - v;
+      float dz, c1, c2;
+      if (h.log_softmax) {
+        const float ls = mine ? (zmine - zmax) - logf(esum) : 0.f;
+        const float lsel = wave_sum(ls * aa);
+        const float ent = wave_sum(mine ? s * ls : 0.f);
+        const float asum = wave_sum(aa);
+        c1 = lsel * adv;
+        c2 = -h.beta * ent;
+        dz = -adv * (aa - s * asum) + h.beta * s * (ls - ent);
+      } else {
+        const float sel = wave_sum(mine ? p * aa : 0.f);
+        const float logp = logf(fmaxf(p, h.log_eps));
+        c1 = logf(fmaxf(sel, h.log_eps)) * adv;
+        c2 = -h.beta * wave_sum(mine ? logp * p : 0.f);
+        const float gsel = sel >= h.log_eps ? 1.0f / sel : 0.f;
+        const float gp = -(adv * gsel) * aa + h.beta * (logp + (p >= h.log_eps ? 1.0f : 0.f));
+        const float gs = mine ? gp / denom : 0.f;
+        const float dot = wave_sum(gs * s);
+        dz = s * (gs - dot);
       }
+      if (mine) h.dz[(size_t)b * h.A + lane] = dz;
+      {
+        const float dvv = v - yy;
+        f32x4 dd = {dvv * wv4[0], dvv * wv4[1], dvv * wv4[2], dvv * wv4[3]};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dd[q] = d[q] > 0.f ? dd[q] : 0.f;
-      *reinterpret_cast<f32x4*>(h.dd1 + (size_t)b * HID + 4 * lane) = dd;
-    }
-    if (lane == 0) {
-      h.dv[b] = v - y;
-      h.lossrow[(size_t)b * 3 + 0] = c1;
-      h.lossrow[(size_t)b * 3 + 1] = c2;
-      h.lossrow[(size_t)b * 3 + 2] = 0.5f * (y - v) * (y - v);
+        for (int o = 0; o < AMAX; ++o) {
+          const float dzo = __shfl(dz, o, 64);          // 0 for lanes >= A
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dd[q] += dzo * wreg[q][o];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dd[q] = d[q] > 0.f ? dd[q] : 0.f;
+        *reinterpret_cast<f32x4*>(h.dd1 + (size_t)b * HID + 4 * lane) = dd;
+      }
+      if (lane == 0) {
+        h.dv[b] = v - yy;
+        h.lossrow[(size_t)b * 3 + 0] = c1;
+        h.lossrow[(size_t)b * 3 + 1] = c2;
+        h.lossrow[(size_t)b * 3 + 2] = 0.5f * (yy - v) * (yy - v);
+      }
     }
   }
+}
+
+template <bool TRAIN, int AMAX>
+__global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= h.B) return;   // wave-uniform
+  const int rows[1] = {b};
+  heads_rows<TRAIN, AMAX, 1>(h, rows, threadIdx.x & 63);
+}
+
+// ---- dense1 forward + heads in ONE launch: dense1_fwd_tile_kernel<1>'s workgroups, and the LAST of the 2*ks workgroups of
+// a 16-row tile to arrive (device-scope counter behind a release fence) runs heads for those rows (two per wave), reading
+// the slabs in slice order exactly as heads_kernel does: same bits.  No workgroup waits for another.
+template <bool TRAIN, int AMAX>
+__global__ __launch_bounds__(512) void dense1_heads_kernel(const float* __restrict__ flat, const float* __restrict__ pk,
+                                                           float* part, int B, int ks_total, int max_steps, HeadArgs h,
+                                                           unsigned* arrive) {
+  extern __shared__ __attribute__((aligned(16))) float d1f_lds[];
+  __shared__ int is_last;
+  float* wls = d1f_lds;                                    // [step][8 column tiles][16 n][16 kk]
+  float* als = d1f_lds + max_steps * 8 * 256;              // [16 rows][260]
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+  const int nrow = (B + 15) / 16;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int rb = j % nrow, yz = (j / nrow) * 8 + xcd;      // yz = ks * 2 + column half (blocks of one slice share an XCD)
+  if (yz >= ks_total * 2) return;                          // block-uniform; such blocks are not counted below
+  const int m0 = rb * 16, ks = yz >> 1, half = yz & 1;
+  const int s0 = (ks * KSTEPS_DENSE) / ks_total, s1 = ((ks + 1) * KSTEPS_DENSE) / ks_total, steps = s1 - s0;
+  for (int p = wv; p < steps * 8; p += 8) {
+    const int sl = p >> 3, nt = p & 7;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pk + ((size_t)(s0 + sl) * HID + half * 128 + nt * 16) * 16 + 4 * lane),
+                                     (__attribute__((address_space(3))) void*)(wls + p * 256), 16, 0, 0);
+  }
+  for (int row = wv; row < 16; row += 8) {
+    if (m0 + row < B) {                                     // wave-uniform
+      if (4 * lane < 16 * steps)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(flat + (size_t)(m0 + row) * FLAT + 16 * s0 + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(als + row * D1F_AS), 16, 0, 0);
+    } else {
+      *reinterpret_cast<f32x4*>(&als[row * D1F_AS + 4 * lane]) = zero4();
+    }
+  }
+  __syncthreads();                                           // vmcnt(0) precedes the barrier: the DMA has landed
+  f32x4 acc[2] = {zero4(), zero4()};
+  const float* bp = wls + (wv * 16 + r) * 16 + 4 * g;
+  const float* ap = als + r * D1F_AS + 4 * g;
+  for (int sl = 0; sl < steps; ++sl) {
+    const f32x4 w = ld4(bp + sl * 8 * 256);
+    const f32x4 a = ld4(ap + 16 * sl);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t & 1] = mfma(a[t], w[t], acc[t & 1]);
+  }
+  float* out = part + ((size_t)ks * B) * HID + half * 128 + wv * 16 + r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int mr = m0 + 4 * g + q;
+    if (mr < B) out[(size_t)mr * HID] = acc[0][q] + acc[1][q];
+  }
+  // ---- the seam: slabs out (barrier: every wave's stores are issued and complete), one release fence and one arrival
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this XCD's L2 -> memory: the slabs are visible device-wide
+    const unsigned old = __hip_atomic_fetch_add(&arrive[rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = old == (unsigned)(2 * ks_total - 1);
+    if (is_last) arrive[rb] = 0;                             // the next launch on this lane starts from zero (stream order)
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // the other workgroups' slabs came through other XCDs' L2s
+  const int r0 = m0 + wv, r1 = m0 + wv + 8;
+  const int rows[2] = {r0 < B ? r0 : -1, r1 < B ? r1 : -1};
+  heads_rows<TRAIN, AMAX, 2>(h, rows, lane);
 }
 
 // ------------------------------------------------------------------ heads backward (weight gradients)
