@@ -338,7 +338,8 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
 
 // overlap: the caller will apply the gradients right away (train, not compute_grads): start their all-reduce as soon as
 // each part of the arena is final; returns with the train stream already waiting for the exchange
-int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = false, const FusedUpd* fu = nullptr) {
+// keep_dn1: also store dn1 (consumed on chip by the fused conv backward; kept in HBM for ga3c_net_fetch after compute_grads)
+int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = false, const FusedUpd* fu = nullptr, bool keep_dn1 = true) {
   const int A = net->A;
   const float* th = net->theta[idx];
   FusedUpd upd;
@@ -372,14 +373,14 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   int nch1, nch2;
   if (net->conv_bwd_fused && B <= 128) {   // one workgroup per CU: beyond one round the tail of the second costs more than the fusion saves
     // conv2_dw + conv2_dx + conv1_dw of a sample half in ONE workgroup (conv_bwd_kernel): dn1 never leaves the chip between them
-    const int grid = 2 * B < 256 ? 2 * B : 256;     // (sample group, half); one slab pair per workgroup
+    const int grid = 2 * B;                         // (sample, half); one slab pair per workgroup
     const size_t lds = CB_LDS_FLOATS * sizeof(float);
     if (t.f.x_u8)
       hipLaunchKernelGGL(conv_bwd_kernel<true>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.xu8, t.f.n1, t.dn2,
-                         net->theta_pk[idx] + PK_W2DX, t.dn1, t.slab2, t.slab1, B);
+                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B);
     else
       hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.x, t.f.n1, t.dn2,
-                         net->theta_pk[idx] + PK_W2DX, t.dn1, t.slab2, t.slab1, B);
+                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B);
     nch1 = nch2 = grid;
   } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
@@ -591,7 +592,7 @@ int train_grads(ga3c_net* net, TrainLane& t, int B, float beta, bool will_apply 
     fu.lr = lr; fu.omr = 1.0f - net->cfg.rmsprop_decay; fu.mu = net->cfg.rmsprop_momentum; fu.eps = net->cfg.rmsprop_epsilon;
     fu.on = 1;
   }
-  CHK(launch_backward(net, t, idx, B, t.exchanged, fuse ? &fu : nullptr));
+  CHK(launch_backward(net, t, idx, B, t.exchanged, fuse ? &fu : nullptr, !will_apply));
   t.stepped = fuse;
   t.stepped_other = other;
   return GA3C_OK;
@@ -1771,6 +1772,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
                             (const int64_t*)nullptr);
+    } else if (k == "conv_stack_fwd_train") {
+      hipExtLaunchKernelGGL((conv_stack_fwd_kernel<true, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
+                            (const int64_t*)nullptr);
     } else if (k == "conv_stack_fwd_u8") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
@@ -1813,7 +1818,8 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.dx_mt = dense_dx_mt(B);
       TL(dense1_bwd_kernel, dim3(d.dw_blocks + d.dx_gx * (((B + 16 * d.dx_mt - 1) / (16 * d.dx_mt) + 3) / 4)), d);
     } else if (k == "conv_bwd") {
-      hipExtLaunchKernelGGL(conv_bwd_kernel<false>, dim3(2 * B < 256 ? 2 * B : 256), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
+      if (B > 128) return fail(GA3C_EINVAL, "conv_bwd runs up to 128 rows");
+      hipExtLaunchKernelGGL(conv_bwd_kernel<false>, dim3(2 * B), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, t.f.n1, t.dn2, net->theta_pk[net->latest] + PK_W2DX, t.dn1, t.slab2,
                             t.slab1, B);
     } else if (k == "dense1_bwd_tile") {

@@ -464,7 +464,6 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
           const int ir = em[q] >> 8, jr = em[q] & 255;
           const float val = fmaxf(acc0[q] + acc1[q] + bv, 0.f);
           n1l[((ir - n1org) * C2_PW + jr + 1) * C1 + r] = val;
-          if (TRAIN && ir >= n1own0 && ir < n1own1) n1[((size_t)b * P1 + ir * O1 + jr) * C1 + r] = val;
         }
       }
     }
@@ -477,6 +476,13 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   GA3C_STAMP(5);
   __syncthreads();
   GA3C_STAMP(6);
+  if (TRAIN) {   // the rows of n1 this half owns (each row exactly once), out of the LDS image as whole 16-byte pieces; under conv2
+    const int row = threadIdx.x / (O1 * C1 / 4), c4 = threadIdx.x - row * (O1 * C1 / 4);
+    const int ir = n1own0 + row;
+    if (ir < n1own1)
+      *reinterpret_cast<f32x4*>(n1 + ((size_t)b * P1 + ir * O1) * C1 + 4 * c4) =
+          *reinterpret_cast<const f32x4*>(n1l + ((ir - n1org) * C2_PW + 1) * C1 + 4 * c4);
+  }
   // ---- conv2 from the LDS image: items = (16-pixel tile, 16-column half), 8 per workgroup
   {
     const int nitem = 2 * ((c2npix + 15) >> 4);
@@ -1692,8 +1698,8 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
 // three grids of load round trips and two kernel boundaries (6.1 + 5.8 + 8.6 us at batch 128).  Here a workgroup (16 waves)
 // = (sample, half):
 //   phase 1  the dn1 pixels it OWNS = the transposed conv of dn2, by output-pixel parity class (conv2_dx_tiles'
-//            arithmetic), ReLU mask from the n1 image in LDS; the result stays in LDS (and goes to HBM once, for
-//            ga3c_net_fetch).  Ownership is by pixel -- rows 0..9 and row 10 up to column 17 | the rest -- so that every
+//            arithmetic), ReLU mask from the n1 image in LDS; the result stays in LDS (and goes to HBM only for
+//            ga3c_net_fetch: compute_grads keeps it, train steps pass dn1 = nullptr).  Ownership is by pixel -- rows 0..9 and row 10 up to column 17 | the rest -- so that every
 //            class of either half fits 4 tiles of 16 pixels: 16 tiles, one per wave (rows 0..10 | 11..20 gave one half 17
 //            tiles, i.e. one wave a second tile of two pixels that everybody waited for).  The ragged class lists live in
 //            an LDS table written once per workgroup.
@@ -1701,17 +1707,19 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
 //            the 64 pixel slots): every (dn2, n1) operand fetch and its pixel -> (row, column) arithmetic feeds 4 MFMAs
 //   phase 3  dW1 partial over n1 rows 0..10 | 10..20 in bands of 3 rows (a pixel of row 10 the half does not own is a
 //            zero in its dn1 image): wave = (4 m-tiles, quarter of the band's 64 pixel slots), conv1_dw_kernel's blocking;
-//            the x bands (16 padded rows, 22.5 KB) are requested by LDS-DMA behind the first barrier and two bands ahead
+//            the half's 48 padded x rows (66 KB) are requested by LDS-DMA behind the first barrier, in flight under
+//            phases 1 and 2, so that the bands run back to back without a barrier
 //   (a first version gave every wave one m-tile / one position: one operand pair and one index computation per MFMA made
 //   phases 2 and 3 VALU-bound, 26.8 us against 22.9 us for the three launches)
-// The K-split partial sums of the waves are folded through LDS once, after the last sample.  Partial dW2 / dW1 (+ bias
+// The K-split partial sums of the waves are folded through LDS once, at the end.  Partial dW2 / dW1 (+ bias
 // tails) go to slab2 / slab1 in conv2_dw's / conv1_dw's layout; slab_reduce_kernel is unchanged.
 constexpr int CB_N1IMG = CS_N1ROWS * C2_PW * C1;             // 5376 floats
 constexpr int CB_DN2IMG = C2DX_DN;                           // 5184: cells of 36 floats (bank spread, see C2DX_CELL)
 constexpr int CB_W2 = 4 * C2DX_W;                            // 8192
 constexpr int CB_DN1 = 11 * O1 * C1;                         // 3696: n1 rows 0..10 | 10..20, [row][col][16]
-constexpr int CB_XBAND = C1_RIN * C1_PW * 4;                 // 5632 floats per band buffer
-constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + 2 * CB_XBAND + 256;   // 33968 floats = 135,872 B
+constexpr int CB_XROWS = 4 * 11 + 4;                         // x rows 4 r0 - 2 .. 4 r0 + 45 of the half's 11 n1 rows
+constexpr int CB_XIMG = CB_XROWS * C1_PW * 4;                // 16896 floats: the whole x image of the half, padded
+constexpr int CB_LDS_FLOATS = CB_N1IMG + CB_DN2IMG + CB_W2 + CB_DN1 + CB_XIMG + 256;   // 39600 floats = 158,400 B
 constexpr int CB_ROW10_CUT = 18;                             // row 10: columns < 18 belong to half 0
 
 // slot m of parity class (py, px) of half h -> (y << 8) | x, or -1
@@ -1739,10 +1747,11 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   float* dnimg = n1img + CB_N1IMG;                           // [12][12][32]  dn2 (i+1, j+1), zero row / column 0
   float* w2l = dnimg + CB_DN2IMG;                            // [4 classes][32][64]
   float* dn1l = w2l + CB_W2;                                 // [11 rows][21][16]
-  float* xb = dn1l + CB_DN1;                                 // 2 x [16][88][4]
-  int* ptab = reinterpret_cast<int*>(xb + 2 * CB_XBAND);     // [4 classes][64 slots]
+  float* xb = dn1l + CB_DN1;                                 // [48][88][4]
+  int* ptab = reinterpret_cast<int*>(xb + CB_XIMG);          // [4 classes][64 slots]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int h = blockIdx.x & 1, grp = blockIdx.x >> 1, ngrp = gridDim.x >> 1;
+  const int h = blockIdx.x & 1, grp = blockIdx.x >> 1;
+  if (grp >= B) return;                                      // block-uniform
   const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;   // conv2 pixels of this half
   const int c2r0 = h ? 5 : 0, n1org = 2 * c2r0 - 1;          // n1 image row 0 holds n1 row n1org
   const int r0 = h ? 10 : 0;                                 // first n1 row of its dn1 image; 11 rows, 4 bands
@@ -1763,24 +1772,24 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   f32x4 acc2[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};          // [position of the pair][column half]
   f32x4 acc1[4] = {zero4(), zero4(), zero4(), zero4()};                 // [m-tile of the group]
   float bs2a = 0.f, bs2b = 0.f, bs1 = 0.f;
-  auto stage_band = [&](int b, int k) {                      // x rows of band k of sample b -> xb[k & 1]
-    float* buf = xb + (k & 1) * CB_XBAND;
-    const int y_base = 4 * (r0 + C1_HB * k) - 2;
-    for (int idx = threadIdx.x; idx < C1_RIN * C1_PW; idx += 1024) {
+  auto stage_x = [&](int b) {                                // the half's x rows of sample b -> xb (phase 3 reads them)
+    const int y_base = 4 * r0 - 2;
+    for (int idx = threadIdx.x; idx < CB_XROWS * C1_PW; idx += 1024) {
       const int row = idx / C1_PW, col = idx - row * C1_PW;
       const int yy = y_base + row, xx = col - 2;
       const bool ok = (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
       if (U8) {
-        *reinterpret_cast<f32x4*>(&buf[idx * 4]) = ok ? load_px<true>(x, b, yy * IMG + xx) : zero4();
+        *reinterpret_cast<f32x4*>(&xb[idx * 4]) = ok ? load_px<true>(x, b, yy * IMG + xx) : zero4();
       } else if (ok) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const float*>(x) + (size_t)b * XS + (size_t)(yy * IMG + xx) * 4),
-                                         (__attribute__((address_space(3))) void*)(buf + (size_t)(idx - lane) * 4), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(xb + (size_t)(idx - lane) * 4), 16, 0, 0);
       } else {
-        *reinterpret_cast<f32x4*>(&buf[idx * 4]) = zero4();
+        *reinterpret_cast<f32x4*>(&xb[idx * 4]) = zero4();
       }
     }
   };
-  for (int b = grp; b < B; b += ngrp) {
+  {
+    const int b = grp;                                       // one sample per workgroup: the grid is 2 * B (B <= 128, one round)
     // ---- stage what phases 1 and 2 read: n1 image (cells of 64 B, 4 lanes each), dn2 image (cells of 128 B, 8 lanes each);
     // clear the dn1 image (row 10's pixels of the other half stay zero)
     const float* n1b = n1 + (size_t)b * N1S;
@@ -1797,10 +1806,10 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       *reinterpret_cast<f32x4*>(&dnimg[((i2 + 1) * 12 + j2 + 1) * C2DX_CELL + 4 * (threadIdx.x & 7)]) = ld4(db + 4 * threadIdx.x);
     }
     if (threadIdx.x < CB_DN1 / 4) *reinterpret_cast<f32x4*>(&dn1l[4 * threadIdx.x]) = zero4();
+    if (U8) stage_x(b);                                      // 17 KB of uint8 per half: with the other loads, converted on the way
     __syncthreads();                                         // vmcnt(0) precedes the barrier: the images have landed
     GA3C_STAMP(1);
-    stage_band(b, 0);                                        // in flight during phases 1 and 2
-    stage_band(b, 1);
+    if (!U8) stage_x(b);                                     // 66 KB by LDS-DMA, in flight during phases 1 and 2
     GA3C_STAMP(2);
     // ---- phase 1: the 16 tiles of its dn1 pixels; wave = (class wv / 4, tile wv % 4)
     {
@@ -1838,7 +1847,7 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
           const float keep = n1img[((y2 - n1org) * C2_PW + x2 + 1) * C1 + r];
           const float val = keep > 0.f ? c0[q] + c1[q] : 0.f;
           dn1l[((y2 - r0) * O1 + x2) * C1 + r] = val;
-          dn1[(size_t)b * N1S + (y2 * O1 + x2) * C1 + r] = val;
+          if (dn1) dn1[(size_t)b * N1S + (y2 * O1 + x2) * C1 + r] = val;    // nullptr: nobody will fetch it (train steps)
         }
       }
     }
@@ -1877,44 +1886,55 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       }
     }
     GA3C_STAMP(4);
-    __syncthreads();                                         // dn1 of the half is complete in LDS; x bands 0, 1 have landed
+    __syncthreads();                                         // dn1 of the half is complete in LDS; its x rows have landed
     GA3C_STAMP(5);
-    // ---- phase 3: dW1 partial, band by band; wave = (m-tiles 4*mg .. 4*mg+3, K quarter kq: pixel slots 16*kq .. 16*kq+15)
-#pragma unroll 1
-    for (int k = 0; k < NBAND; ++k) {
-      const float* img = xb + (k & 1) * CB_XBAND;
-      const int brow0 = C1_HB * k;                           // first image row of the band
-      const int bpix = (NROWS - brow0 < C1_HB ? NROWS - brow0 : C1_HB) * O1;       // 63; 42 in the last band
+    // ---- phase 3: dW1 partial, band by band (no barrier between bands: the whole x image is resident);
+    // wave = (m-tiles 4*mg .. 4*mg+3, K quarter kq: pixel slots 16*kq .. 16*kq+15)
+    {
       const int mg = wv & 3, kq = wv >> 2;
-      float av[4][4], bv[4];
+      float av[2][4][4], bv[2][4];
+      auto load_band = [&](int k, float (&a4)[4][4], float (&b4)[4]) {
+        const int brow0 = C1_HB * k;                         // first image row of the band
+        const float* img = xb + (4 * brow0) * (C1_PW * 4);
+        const int bpix = (NROWS - brow0 < C1_HB ? NROWS - brow0 : C1_HB) * O1;       // 63; 42 in the last band
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int q = 16 * kq + 4 * t + g;
-        const bool ok = q < bpix;
-        const int qc = ok ? q : 0;
-        const int il = qc / O1, j = qc - il * O1;
-        bv[t] = ok ? dn1l[(brow0 * O1 + q) * C1 + r] : 0.f;
-        const float* ap = img + (4 * il) * (C1_PW * 4) + 16 * j + r;
+        for (int t = 0; t < 4; ++t) {
+          const int q = 16 * kq + 4 * t + g;
+          const bool ok = q < bpix;
+          const int qc = ok ? q : 0;
+          const int il = qc / O1, j = qc - il * O1;
+          b4[t] = ok ? dn1l[(brow0 * O1 + q) * C1 + r] : 0.f;
+          const float* ap = img + (4 * il) * (C1_PW * 4) + 16 * j + r;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const int mt = mg * 4 + mi;                        // u = mt >> 1, v half = mt & 1
-          av[t][mi] = ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16];
+          for (int mi = 0; mi < 4; ++mi) {
+            const int mt = mg * 4 + mi;                      // u = mt >> 1, v half = mt & 1
+            a4[t][mi] = ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16];
+          }
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          pin(b4[t]);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) pin(a4[t][mi]);
+        }
+      };
+      auto band_mfma = [&](const float (&a4)[4][4], const float (&b4)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bs1 += b4[t];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc1[mi] = mfma(a4[t][mi], b4[t], acc1[mi]);
+        }
+      };
+      static_assert(NBAND % 2 == 0, "bands are processed in pairs");
+      load_band(0, av[0], bv[0]);
+#pragma unroll 1
+      for (int k = 0; k < NBAND; k += 2) {                   // the next band's operands are fetched under this band's MFMAs
+        load_band(k + 1, av[1], bv[1]);
+        band_mfma(av[0], bv[0]);
+        if (k + 2 < NBAND) load_band(k + 2, av[0], bv[0]);
+        band_mfma(av[1], bv[1]);
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        pin(bv[t]);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) pin(av[t][mi]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        bs1 += bv[t];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc1[mi] = mfma(av[t][mi], bv[t], acc1[mi]);
-      }
-      __syncthreads();                                       // band k has been read; band k+1 has landed
-      if (k + 2 < NBAND) stage_band(b, k + 2);
     }
     GA3C_STAMP(6);
   }

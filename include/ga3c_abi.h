@@ -127,7 +127,8 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
                          float* elapsed_ms);
 
 /* Activations / per-sample gradients of the last resident or train-lane step, for parity tests:
- * name in {"n1","n2","d1","z","p","v","dz","dv","dd1","dn2","dn1"}. */
+ * name in {"n1","n2","d1","z","p","v","dz","dv","dd1","dn2","dn1"}.  "dn1" is that of the last ga3c_net_compute_grads
+ * (train steps of up to 128 rows consume it on chip and do not store it). */
 int ga3c_net_fetch(ga3c_net* net, const char* name, float* out, int64_t count);
 
 /* Zero-copy intake from the shared-memory transport (include/ga3c_host.h): register the whole segment

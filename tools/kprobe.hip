@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(pk, hw.data(), 8192 * 4, hipMemcpyHostToDevice));
     const size_t cl = CB_LDS_FLOATS * sizeof(float);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl));
-    const int grid = 2 * B < 256 ? 2 * B : 256;
+    const int grid = 2 * B;
     for (int it = 0; it < 4; ++it) {
       CK(hipMemsetAsync(sb, 0, (size_t)nwg * 16 * 16 * 8, st));
       hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), cl, st, (const void*)x, n1, dn2, pk, dn1, slab2, slab1, B);

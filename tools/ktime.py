@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: per-launch time of named kernels (ga3c_net_time_kernel), interleaved rounds, median and min.
-usage: python tools/ktime.py [--batch B] name [name ...]"""
+usage: python tools/ktime.py [--batch B] name [name ...]      (@predict / @train: whole steps, one lane)"""
 import argparse
 import os
 import sys
@@ -37,6 +37,10 @@ def main():
     res = {n: [] for n in args.names}
     for _ in range(args.rounds):
         for n in args.names:
+            if n in ("@predict", "@train"):                # whole steps on one lane, inputs resident (ga3c_net_time_resident)
+                nat.check(lib.ga3c_net_time_resident(h, 0 if n == "@predict" else 1, B, 200, 3e-4, 0.01, nat.C.byref(ms)), n)
+                res[n].append(ms.value / 200 * 1e3)
+                continue
             nat.check(lib.ga3c_net_time_kernel(h, n.encode(), B, 30, nat.C.byref(ms)), n)
             res[n].append(ms.value / 30 * 1e3)
     for n in args.names:
