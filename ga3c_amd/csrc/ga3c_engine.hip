@@ -931,6 +931,11 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   HIPCHK(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(GA3C_EINVAL, "device %d not in [0,%d)", cfg->device, ndev);
   HIPCHK(hipSetDevice(cfg->device));
+  // How a host thread waits for its stream: HIP's default spins (lowest latency, one core per waiting thread); with more
+  // batching threads than the process has cores to spare, GA3C_BLOCKING_SYNC=1 makes them sleep on the completion interrupt.
+  if (const char* e = getenv("GA3C_BLOCKING_SYNC")) {
+    if (atoi(e) != 0 && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+  }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)

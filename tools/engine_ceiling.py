@@ -1,0 +1,102 @@
+"""The engine's ceiling: the Server with its predictor / trainer threads and the HIP network, fed by NATIVE agent threads
+(tools/native_agents.cpp: the agent side of the C ABI, an "emulator" that is one memcpy) instead of Python ProcessAgents.
+What is left is the transport, the batching threads and the GPU, with states crossing PCIe out of the registered segment.
+
+    python tools/engine_ceiling.py --agents 256 --predictors 2 --trainers 2 --seconds 12 [--no-train]
+
+Prints one JSON line.  Development aid; not part of the product or the test suite.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def build_tool():
+    exe = os.path.join(ROOT, "tools", "native_agents")
+    src = exe + ".cpp"
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
+                               "-L", os.path.join(ROOT, "ga3c_amd"), "-lga3c_host", "-Wl,-rpath," + os.path.join(ROOT, "ga3c_amd")])
+    return exe
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=256)
+    ap.add_argument("--predictors", type=int, default=2)
+    ap.add_argument("--trainers", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--warm", type=float, default=4.0)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--train-min-batch", type=int, default=127)
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--hogwild", action="store_true")
+    args = ap.parse_args()
+    exe = build_tool()
+
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    from Server import Server
+
+    Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = 0, args.predictors, args.trainers
+    Config.DYNAMIC_SETTINGS = False
+    Config.PREDICTION_BATCH_SIZE = args.batch
+    Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
+    Config.TRAIN_MODELS = not args.no_train
+    Config.HOGWILD = bool(args.hogwild)
+    Config.SAVE_MODELS = False
+    Config.LOAD_CHECKPOINT = False
+    Config.RESULTS_FILENAME = "/tmp/engine_ceiling_results.txt"
+    Config.EPISODES = 10 ** 9
+
+    srv = Server(max_agents=args.agents)
+    snap = {}
+
+    def take():
+        return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step,
+                "batches": sum(p.batches for p in srv.predictors),
+                "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")},
+                "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive())}
+
+    out = {}
+
+    def driver():
+        time.sleep(1.0)                                   # predictors and trainers are up
+        proc = subprocess.Popen([exe, srv.transport.name, str(args.agents), str(args.seconds - 2.0), "0" if args.no_train else "1"],
+                                stdout=subprocess.PIPE, text=True)
+        time.sleep(args.warm)
+        snap["a"] = take()
+        time.sleep(max(0.5, args.seconds - 2.0 - args.warm - 1.0))
+        snap["b"] = take()
+        out["tool"] = proc.communicate(timeout=30)[0].strip().replace("\n", " | ")
+
+    th = threading.Thread(target=driver, daemon=True)
+    th.start()
+    srv.main(max_seconds=args.seconds)
+    th.join(timeout=40)
+    a, b = snap.get("a"), snap.get("b")
+    if not a or not b:
+        print(json.dumps({"error": "sampler did not finish"}))
+        return
+    dt = b["t"] - a["t"]
+    pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
+    state_bytes = 84 * 84 * 4
+    print(json.dumps({
+        "agents": args.agents, "native_agents": True, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
+        "hogwild": bool(args.hogwild), "window_s": round(dt, 2), "host_cores": os.cpu_count(),
+        "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
+        "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),
+        "predictor_us_per_batch": {k: round((b["loop"][k] - a["loop"][k]) / batches * 1e6, 1) for k in b["loop"]},
+        "pcie_gb_per_s_states": round(pred / dt * state_bytes / 1e9, 2), "threads_died": b["died"], "tool": out.get("tool")}))
+
+
+if __name__ == "__main__":
+    main()

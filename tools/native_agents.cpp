@@ -1,0 +1,99 @@
+// tools/native_agents.cpp -- development aid: the engine's ceiling when actors cost (almost) nothing.
+// N threads act as agents 0..N-1 of a running Server through the C ABI of include/ga3c_host.h, exactly as ProcessAgent does
+// (ProcessAgent.py:102-107,117-162,175 of the reference): write a fresh uint8 state into the slot, submit, sleep on the
+// slot's futex for (p, v), draw the action from p, and every TIME_MAX steps ship a rollout (states, returns, actions) to the
+// training queue.  The "emulator" is a memcpy out of a pool of random frames, so what is measured is the transport, the
+// batching predictors / trainers and the GPU -- not Python.  Not part of the product or of the test suite.
+//   g++ -O2 -std=c++17 -pthread -I include -o tools/native_agents tools/native_agents.cpp -L ga3c_amd -lga3c_host -Wl,-rpath,$PWD/ga3c_amd
+//   tools/native_agents <segment name> <agents> <seconds> <train 0|1>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "ga3c_host.h"
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: %s <segment> <agents> <seconds> <train 0|1>\n", argv[0]); return 2; }
+  const char* name = argv[1];
+  const int n = atoi(argv[2]);
+  const double seconds = atof(argv[3]);
+  const bool train = atoi(argv[4]) != 0;
+  ga3c_shm* shm = nullptr;
+  if (ga3c_shm_attach(name, &shm) != 0) { fprintf(stderr, "attach: %s\n", ga3c_host_last_error()); return 1; }
+  ga3c_shm_config cfg;
+  ga3c_shm_get_config(shm, &cfg);
+  if (n > cfg.max_agents || cfg.rollout_row_bytes != 0) { fprintf(stderr, "segment does not fit (%d agents max)\n", cfg.max_agents); return 1; }
+  const size_t sb = (size_t)cfg.state_bytes;
+  std::vector<unsigned char> pool(64 * sb);
+  std::mt19937_64 rng(12345);
+  for (size_t i = 0; i + 8 <= pool.size(); i += 8) { const unsigned long long r = rng(); memcpy(&pool[i], &r, 8); }
+  std::atomic<bool> stop{false};
+  std::atomic<long long> steps{0}, rollouts{0}, ns_copy{0}, ns_submit{0}, ns_wait{0};
+  std::vector<std::thread> th;
+  for (int id = 0; id < n; ++id) {
+    th.emplace_back([&, id] {
+      std::mt19937 r(1000 + id);
+      std::vector<float> p(cfg.num_actions);
+      std::vector<int> acts(cfg.train_rows);
+      std::vector<int> frames(cfg.train_rows);
+      float v = 0.f;
+      int t = 0, k = id;
+      unsigned char* slot = static_cast<unsigned char*>(ga3c_pq_state_ptr(shm, id));
+      long long mine = 0;
+      while (!stop.load(std::memory_order_relaxed)) {
+        k = (k + 1) & 63;
+        const auto c0 = std::chrono::steady_clock::now();
+        memcpy(slot, &pool[(size_t)k * sb], sb);               // the emulator's next state
+        const auto c1 = std::chrono::steady_clock::now();
+        if (ga3c_pq_submit(shm, id) != 0) break;
+        const auto c2 = std::chrono::steady_clock::now();
+        int rc;
+        while ((rc = ga3c_pq_wait(shm, id, p.data(), &v, 200)) != 0 && !stop.load(std::memory_order_relaxed))
+          if (rc != GA3C_H_ETIMEOUT) return;
+        if (rc != 0) break;
+        const auto c3 = std::chrono::steady_clock::now();
+        if ((mine & 15) == 0) {                                 // wall time of the three parts of a step, sampled
+          ns_copy.fetch_add((c1 - c0).count(), std::memory_order_relaxed);
+          ns_submit.fetch_add((c2 - c1).count(), std::memory_order_relaxed);
+          ns_wait.fetch_add((c3 - c2).count(), std::memory_order_relaxed);
+        }
+        float u = std::generate_canonical<float, 24>(r), c = 0.f;
+        int a = cfg.num_actions - 1;
+        for (int i = 0; i < cfg.num_actions; ++i) { c += p[i]; if (u < c) { a = i; break; } }
+        acts[t] = a; frames[t] = k;
+        ++mine;
+        if (++t == cfg.train_rows - 1) {                        // TIME_MAX steps: ship the rollout
+          if (train) {
+            int s;
+            while ((s = ga3c_tq_acquire(shm, 200)) < 0 && !stop.load(std::memory_order_relaxed))
+              if (s != GA3C_H_ETIMEOUT) return;
+            if (s < 0) break;
+            unsigned char* st = static_cast<unsigned char*>(ga3c_tq_states(shm, s));
+            float* ret = ga3c_tq_returns(shm, s);
+            int32_t* ac = ga3c_tq_actions(shm, s);
+            for (int i = 0; i < t; ++i) { memcpy(st + (size_t)i * sb, &pool[(size_t)frames[i] * sb], sb); ret[i] = 0.01f * (float)(i - 2); ac[i] = acts[i]; }
+            ga3c_tq_commit(shm, s, t);
+            rollouts.fetch_add(1, std::memory_order_relaxed);
+          }
+          t = 0;
+        }
+        if ((mine & 63) == 0) { steps.fetch_add(64, std::memory_order_relaxed); }
+      }
+    });
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+  stop.store(true);
+  for (auto& t : th) t.join();
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double samples = (double)steps.load() / 16.0 + 1.0;
+  printf("{\"agent_steps\": %lld, \"rollouts\": %lld, \"seconds\": %.3f, \"us_per_step\": {\"state_copy\": %.1f, \"submit\": %.1f, \"wait\": %.1f}}\n",
+         steps.load(), rollouts.load(), dt, ns_copy.load() / samples * 1e-3, ns_submit.load() / samples * 1e-3, ns_wait.load() / samples * 1e-3);
+  ga3c_shm_close(shm, 0);
+  return 0;
+}
