@@ -882,6 +882,44 @@ int ga3c_tq_pop(ga3c_shm* shm, int32_t timeout_ms) {
   return rc == GA3C_H_OK ? (int)slot : rc;
 }
 
+int ga3c_tq_collect(ga3c_shm* shm, int32_t min_rows, int32_t timeout_ms, int32_t hold_timeout_ms, int32_t* rows,
+                    int32_t* n_slots, int32_t* slots, int64_t* row_offsets, float* returns, int32_t* actions,
+                    int32_t cap_rows, int32_t cap_slots) {
+  if (!shm || !rows || !n_slots || !slots || !row_offsets || !returns || !actions) return fail(GA3C_H_EINVAL, "null argument");
+  Header* h = shm->hdr();
+  if (*rows < 0 || *n_slots < 0 || min_rows < 0) return fail(GA3C_H_EINVAL, "bad batch state");
+  const int64_t row_bytes = h->cfg.rollout_row_bytes ? h->cfg.rollout_row_bytes : h->cfg.state_bytes;
+  while (*rows <= min_rows) {
+    if (*rows + h->cfg.train_rows > cap_rows || *n_slots >= cap_slots) return fail(GA3C_H_EINVAL, "batch arrays too small");
+    // the caller keeps the slots until the GPU has read them: if the agents have none left and nothing is queued, it
+    // has to give some back first (ThreadTrainer's spill rule)
+    if (*n_slots > 0 && ring_size(&h->freeq) == 0 && ring_size(&h->readyq) == 0) return GA3C_H_ESTARVED;
+    uint32_t slot = 0;
+    const int rc = ring_pop_wait(shm, &h->readyq, &slot, *n_slots > 0 ? hold_timeout_ms : timeout_ms);
+    if (rc != GA3C_H_OK) return rc;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const char* ro = shm->rollout((int)slot);
+    const int32_t n = *reinterpret_cast<const int32_t*>(ro + h->ro_rows_off);
+    const int64_t off0 = (int64_t)(ro - shm->base);
+    for (int32_t i = 0; i < n; ++i) row_offsets[*rows + i] = off0 + i * row_bytes;
+    memcpy(returns + *rows, ro + h->ro_returns_off, (size_t)n * sizeof(float));
+    memcpy(actions + *rows, ro + h->ro_actions_off, (size_t)n * sizeof(int32_t));
+    slots[*n_slots] = (int32_t)slot;
+    *n_slots += 1;
+    *rows += n;
+  }
+  return GA3C_H_OK;
+}
+
+int ga3c_tq_release_many(ga3c_shm* shm, const int32_t* slots, int32_t n) {
+  if (!shm || (!slots && n > 0) || n < 0) return fail(GA3C_H_EINVAL, "bad argument");
+  for (int32_t i = 0; i < n; ++i) {
+    const int rc = ga3c_tq_release(shm, slots[i]);
+    if (rc != GA3C_H_OK) return rc;
+  }
+  return GA3C_H_OK;
+}
+
 int ga3c_tq_rows(ga3c_shm* shm, int32_t slot) {
   if (!shm || slot < 0 || slot >= shm->hdr()->cfg.train_slots) return fail(GA3C_H_EINVAL, "bad slot id");
   return *reinterpret_cast<int32_t*>(shm->rollout(slot) + shm->hdr()->ro_rows_off);

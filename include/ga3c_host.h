@@ -139,6 +139,18 @@ int ga3c_tq_commit(ga3c_shm* shm, int32_t slot, int32_t rows);
 int ga3c_tq_pop(ga3c_shm* shm, int32_t timeout_ms);                     /* -> ready slot id */
 int ga3c_tq_rows(ga3c_shm* shm, int32_t slot);
 int ga3c_tq_release(ga3c_shm* shm, int32_t slot);
+/* The batch assembly of ThreadTrainer.run (ThreadTrainer.py:48-59) in one call, for trainers that let the GPU read the rows out
+ * of the slots: pop rollouts until the batch holds MORE than min_rows rows.  *rows / *n_slots are the state of the batch in
+ * progress (0 / 0 to start one; kept across GA3C_H_ETIMEOUT so that the caller can look at its exit flag and call again).
+ * Per rollout: its slot id -> slots[], the byte offsets of its rows in the segment -> row_offsets[], its returns and actions
+ * -> returns[] / actions[] (row-aligned).  The slots stay the caller's until ga3c_tq_release(_many).  Waits timeout_ms for the
+ * first rollout and hold_timeout_ms once slots are held.  GA3C_H_ESTARVED: slots are held, none is free and none is queued
+ * -- the agents are blocked on the caller, which must give slots back before asking again. */
+#define GA3C_H_ESTARVED 1
+int ga3c_tq_collect(ga3c_shm* shm, int32_t min_rows, int32_t timeout_ms, int32_t hold_timeout_ms, int32_t* rows,
+                    int32_t* n_slots, int32_t* slots, int64_t* row_offsets, float* returns, int32_t* actions,
+                    int32_t cap_rows, int32_t cap_slots);
+int ga3c_tq_release_many(ga3c_shm* shm, const int32_t* slots, int32_t n);
 int ga3c_tq_ready_count(ga3c_shm* shm);
 int ga3c_tq_free_count(ga3c_shm* shm);    /* slots no producer and no consumer holds; 0 = producers are blocked */
 

@@ -190,6 +190,114 @@ def test_trainer_batching_matches_reference_trace(mods, golden_dir, key):
         t.close()
 
 
+class _RowsServer(_Server):
+    """A server whose model reads the rows out of the slots itself (the zero-copy trainer path)."""
+    zero_copy = True
+
+    def __init__(self, transport, n_act, state_dim):
+        super().__init__(transport, n_act, state_dim)
+        import threading
+        self.batch_lock = threading.Lock()
+        self.base = np.frombuffer((nat_buffer(transport)), np.uint8)
+
+    def train_model_rows(self, offsets, r, a, tid):
+        first = [int(self.base[int(o)]) for o in offsets]
+        self.calls.append(dict(rows=len(offsets), r_sum=float(np.sum(r)), first_bytes=first, a_shape=a.shape, a_dtype=str(a.dtype)))
+
+
+def nat_buffer(transport):
+    import ctypes
+    import _native as nat
+    lib = nat.host_lib()
+    n = lib.ga3c_shm_bytes(transport._h)
+    return (ctypes.c_uint8 * n).from_address(lib.ga3c_shm_base(transport._h))
+
+
+@pytest.mark.parametrize("native", [True, False])
+@pytest.mark.parametrize("key", ["trainer_min0", "trainer_min8", "trainer_min127"])
+def test_zero_copy_trainer_assembly_native_and_python_match_reference_trace(mods, golden_dir, key, native):
+    """ga3c_tq_collect (one native call per batch) against the Python loop and the reference's recorded batches: same
+    batch sizes, same returns, and row offsets that point at the rollouts' own bytes in arrival order."""
+    nat, tp, Config = mods
+    from ThreadTrainer import ThreadTrainer
+    g = json.load(open(os.path.join(golden_dir, "batcher_traces.json")))[key]
+    t = tp.Transport.create(tp.unique_name("t_rows"), 2, 4, 16, 64, 6)
+    try:
+        Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = g["min_batch"], native
+        base, want_first = 0, []
+        for n in g["rollout_rows"]:
+            slot = t.acquire(1000)
+            states, returns, actions = t.rollout_views(slot)
+            for i in range(n):
+                states[i] = (base + i) % 251
+                returns[i] = base + i
+                actions[i] = (base + i) % 4
+                want_first.append((base + i) % 251)
+            base += n
+            t.commit(slot, n)
+        srv = _RowsServer(t, 4, (16,))
+        th = ThreadTrainer(srv, 0, t)
+        th.start()
+        deadline = time.time() + 10
+        while len(srv.calls) < len(g["calls"]) and time.time() < deadline:
+            time.sleep(0.01)
+        time.sleep(0.1)
+        th.exit_flag = True
+        th.join(5)
+        assert [c["rows"] for c in srv.calls] == [c["rows"] for c in g["calls"]]
+        assert [c["r_sum"] for c in srv.calls] == [c["r_sum"] for c in g["calls"]]
+        assert sum((c["first_bytes"] for c in srv.calls), []) == want_first[:sum(c["rows"] for c in srv.calls)]
+        assert th.spills == 0
+        assert t.free_count() + t.ready_count() == 64           # every slot the trainer held went back to the free ring
+    finally:
+        Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = 0, True
+        t.shutdown()
+        t.close()
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_zero_copy_trainer_spills_when_the_agents_run_out_of_slots(mods, native):
+    """4 slots, a batch that needs 5 rollouts: the trainer holds all four, nothing is free and nothing is queued -> it must
+    copy what it holds to a host batch and give the slots back (ThreadTrainer's spill rule; ga3c_tq_collect reports it as
+    GA3C_H_ESTARVED)."""
+    nat, tp, Config = mods
+    from ThreadTrainer import ThreadTrainer
+    import threading
+    t = tp.Transport.create(tp.unique_name("t_spill"), 2, 4, 16, 4, 6)
+    try:
+        Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = 24, native      # 5 rollouts of 5 rows = 25 > 24
+        srv = _RowsServer(t, 4, (16,))
+        th = ThreadTrainer(srv, 0, t)
+        th.start()
+
+        def producer():
+            for k in range(5):
+                slot = -3
+                while slot == -3:
+                    slot = t.acquire(200)
+                states, returns, actions = t.rollout_views(slot)
+                for i in range(5):
+                    states[i] = 5 * k + i
+                    returns[i] = 1.0
+                    actions[i] = 0
+                t.commit(slot, 5)
+        pr = threading.Thread(target=producer, daemon=True)
+        pr.start()
+        deadline = time.time() + 10
+        while not srv.calls and time.time() < deadline:
+            time.sleep(0.01)
+        th.exit_flag = True
+        th.join(5)
+        pr.join(5)
+        assert th.spills == 1
+        assert len(srv.calls) == 1 and srv.calls[0]["rows"] == 25 and srv.calls[0]["r_sum"] == 25.0      # host path: train_model
+        assert srv.calls[0]["first"] == 0.0 and srv.calls[0]["last"] == 24.0
+    finally:
+        Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = 0, True
+        t.shutdown()
+        t.close()
+
+
 def test_transport_rejects_double_submit_and_times_out(mods):
     nat, tp, Config = mods
     t = tp.Transport.create(tp.unique_name("t_misc"), 4, 6, 32, 2, 3)
