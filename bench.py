@@ -52,7 +52,8 @@ def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2, trai
     Config.PRINT_STATS_FREQUENCY = 10 ** 9
     Config.RESULTS_FILENAME = os.devnull
     Config.NUM_ACTIONS = A
-    Config.FRAME_SOURCE, Config.FRONTEND = ("planes", "host") if frames == "planes" else ("rgb", frames.split("-")[1])
+    Config.FRAME_SOURCE, Config.FRONTEND = {"planes": ("planes", "host"), "planes-device": ("planes", "device")}.get(
+        frames, ("rgb", frames.split("-")[1]))
     real_stdout = sys.stdout
     sys.stdout = sys.stderr
     try:
@@ -467,6 +468,12 @@ def main():
         r64 = run_engine(None, max(4.0, args.e2e_seconds * 0.75), 2 * args.e2e_agents, B, A)
         out["e2e"]["agents_x2"] = {k: r64[k] for k in ("predictions_per_sec", "training_steps_per_sec", "mean_predict_batch",
                                                         "seconds", "agents", "predictors", "trainers")}
+        # the same 64 agents shipping only their newest 84x84 plane (Config.FRONTEND = 'device' with FRAME_SOURCE = 'planes'):
+        # the 4-deep frame queue and the plane history live in HBM, rollouts name their states -- 7 KB per step over PCIe
+        # instead of 62 KB, and no frame stacking in the agents
+        rpd = run_engine(None, max(4.0, args.e2e_seconds * 0.75), 2 * args.e2e_agents, B, A, frames="planes-device")
+        out["e2e"]["agents_x2_frame_queue_on_device"] = {k: rpd[k] for k in ("predictions_per_sec", "training_steps_per_sec",
+                                                                              "mean_predict_batch", "seconds", "agents", "predictors", "trainers")}
         # the same engine fed with raw 210x160x3 emulator frames: the reference's front-end in the agents (host) against the
         # HIP front-end with device-resident frame queues and (agent, plane) rollouts
         half = max(4.0, args.e2e_seconds * 0.75)

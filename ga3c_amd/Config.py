@@ -93,7 +93,10 @@ class Config:
                                         # front-end (Environment.py:52-74: gray, bytescale, bilinear resize, frame queue)
     FRONTEND = 'host'                   # where that front-end runs for 'rgb' frames: 'host' = in the agent process
                                         # (ga3c_frame_preprocess), states shipped as before; 'device' = the agent ships
-                                        # the raw frame, planes / frame queues / training rows stay in HBM
+                                        # the raw frame, planes / frame queues / training rows stay in HBM.  With 'planes'
+                                        # 'device' keeps only the 4-deep frame queue and the plane history in HBM: the agent
+                                        # ships its newest 84x84 plane (7,056 B per step instead of a 28,224 B state, and
+                                        # nothing at all for training)
     FRAME_HEIGHT = 210
     FRAME_WIDTH = 160
     FRAME_HISTORY = 0                   # planes of history per agent on the device; 0 = derived from the queue bounds

@@ -47,7 +47,7 @@ class Environment:
             shape = self.gym.observation_space.shape
             Config.FRAME_HEIGHT, Config.FRAME_WIDTH = int(shape[0]), int(shape[1])
         self.rgb = Config.FRAME_SOURCE in ('rgb', 'gym')
-        self.on_device = self.rgb and Config.FRONTEND == 'device'
+        self.on_device = Config.FRONTEND == 'device'      # the frame queue lives in HBM: .frame is all the agent holds
         self.frame = None
         self.frames_queued = 0
         self.nb_frames = Config.STACKED_FRAMES
@@ -133,6 +133,10 @@ class Environment:
                                                                 nat.ptr(frame, nat.u8p)), "ga3c_frame_preprocess")
         else:
             frame = np.frombuffer(self.rng.bytes(h * w), np.uint8).reshape(h, w)
+            if self.on_device:                            # ready-made plane, queue kept on the device
+                self.frame = frame
+                self.frames_queued += 1
+                return
         self._stack32 = (self._stack32 >> _U8) | (frame.astype(np.uint32) << _U24)
         self._filled = min(self._filled + 1, self.nb_frames)
 

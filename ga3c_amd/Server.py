@@ -37,10 +37,12 @@ class Server:
         n_state = Config.IMAGE_HEIGHT * Config.IMAGE_WIDTH * Config.STACKED_FRAMES
         state_bytes = n_state if Config.STATE_TRANSPORT == 'u8' else 4 * n_state
         # device-side frame front-end: slots carry the emulator's raw frame, rollout rows only name their state
-        self.device_frontend = Config.FRAME_SOURCE in ('rgb', 'gym') and Config.FRONTEND == 'device'
+        self.device_frontend = Config.FRONTEND == 'device'
+        raw = Config.FRAME_SOURCE in ('rgb', 'gym')         # raw emulator frames; otherwise ready-made 84x84 planes
+        self.frame_shape = (Config.FRAME_HEIGHT, Config.FRAME_WIDTH, 3) if raw else (Config.IMAGE_HEIGHT, Config.IMAGE_WIDTH, 1)
         row_bytes = 0
         if self.device_frontend:
-            state_bytes = (Config.FRAME_HEIGHT * Config.FRAME_WIDTH * 3 + 15) // 16 * 16
+            state_bytes = (self.frame_shape[0] * self.frame_shape[1] * self.frame_shape[2] + 15) // 16 * 16
             row_bytes = 16
         # training_q.get() frees a queue entry at once (ThreadTrainer.py:49); zero-copy trainers keep a rollout's slot
         # until the GPU has read it, so the slots they hold come on top of the queue bound
@@ -68,7 +70,7 @@ class Server:
             # every trainer can hold TRAINING_MIN_BATCH_SIZE + TIME_MAX + 1 such rows, in the worst case of one agent
             history = Config.FRAME_HISTORY or ((self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8 +
                                                max(Config.TRAINERS, 2) * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1))
-            self.model.frames_config(self.max_agents, Config.FRAME_HEIGHT, Config.FRAME_WIDTH, 3, history)
+            self.model.frames_config(self.max_agents, self.frame_shape[0], self.frame_shape[1], self.frame_shape[2], history)
         if Config.LOAD_CHECKPOINT:
             try:
                 self.stats.episode_count.value = self.model.load()

@@ -773,7 +773,8 @@ int launch_frames(ga3c_net* net, const uint8_t* rgb_dev, const int32_t* agents, 
   a.hb = f.hb; a.hk = f.hk; a.vb = f.vb; a.vk = f.vk;
   a.H = f.H; a.W = f.W; a.C = f.C; a.OH = IMG; a.OW = IMG; a.hks = f.hks; a.vks = f.vks;
   if (reinterpret_cast<uintptr_t>(rgb_dev) & 3) return fail(GA3C_EINVAL, "frames: the frame buffer must be 4-byte aligned");
-  if (f.C == 3) hipLaunchKernelGGL(frame_frontend_kernel<3>, dim3(n), dim3(FE_THREADS), f.lds, st, a);
+  if (f.C == 1) hipLaunchKernelGGL(plane_push_kernel, dim3(n), dim3(256), 0, st, a);
+  else if (f.C == 3) hipLaunchKernelGGL(frame_frontend_kernel<3>, dim3(n), dim3(FE_THREADS), f.lds, st, a);
   else hipLaunchKernelGGL(frame_frontend_kernel<4>, dim3(n), dim3(FE_THREADS), f.lds, st, a);
   HIPCHK(hipGetLastError());
   return GA3C_OK;
@@ -1287,8 +1288,10 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
 int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, int32_t width, int32_t channels,
                            int32_t history) {
   if (!net) return fail(GA3C_EINVAL, "null argument");
-  if (max_agents < 1 || height < 1 || width < 1 || (channels != 3 && channels != 4))
-    return fail(GA3C_EINVAL, "frames: need max_agents >= 1, a positive frame size and 3 or 4 channels");
+  if (max_agents < 1 || height < 1 || width < 1 || (channels != 3 && channels != 4 && channels != 1))
+    return fail(GA3C_EINVAL, "frames: need max_agents >= 1, a positive frame size and 3 or 4 channels (1: ready-made planes)");
+  if (channels == 1 && (height != IMG || width != IMG))
+    return fail(GA3C_EINVAL, "frames: one channel means ready-made %dx%d planes", IMG, IMG);
   if (history != 0 && history < 2 * CIN) return fail(GA3C_EINVAL, "frames: a plane history holds at least %d planes", 2 * CIN);
   HIPCHK(hipSetDevice(net->cfg.device));
   Frames& f = net->fr;

@@ -238,6 +238,33 @@ __global__ __launch_bounds__(FE_THREADS) void frame_frontend_kernel(FrameArgs a)
   }
 }
 
+// The same push for frames that ARE planes already (C = 1, H x W = OH x OW: an actor that keeps the reference's gray /
+// bytescale / resize on its side, or a source of ready-made planes): no arithmetic, only the frame queue kept on the device --
+// the actor then ships 7,056 bytes per step instead of a 28,224-byte state, and rollout rows name states in the plane history.
+__global__ __launch_bounds__(256) void plane_push_kernel(FrameArgs a) {
+  const int f = blockIdx.x, nout = a.OH * a.OW;
+  const uint8_t* src = a.src_off ? a.rgb + a.src_off[f] : a.rgb + (size_t)f * nout;
+  const int agent = a.agents ? a.agents[f] : -1;
+  const bool clear = a.reset && a.reset[f];
+  uint32_t* stack = agent >= 0 ? a.stacks + (size_t)agent * nout : nullptr;
+  uint8_t* plane = a.planes ? a.planes + (size_t)f * nout : nullptr;
+  uint8_t* hist = (a.ring && agent >= 0) ? a.ring + ((size_t)agent * a.hist + a.ring_slot[f]) * nout : nullptr;
+  for (int p0 = 4 * threadIdx.x; p0 < nout; p0 += 4 * 256) {       // nout % 4 == 0 (checked on the host)
+    uint4 s = make_uint4(0, 0, 0, 0);
+    if (stack && !clear) s = *reinterpret_cast<const uint4*>(stack + p0);
+    const uint32_t px4 = *reinterpret_cast<const uint32_t*>(src + p0);
+    if (plane) *reinterpret_cast<uint32_t*>(plane + p0) = px4;
+    if (hist) *reinterpret_cast<uint32_t*>(hist + p0) = px4;
+    if (stack) {
+      s.x = (s.x >> 8) | ((px4 & 255u) << 24);
+      s.y = (s.y >> 8) | (((px4 >> 8) & 255u) << 24);
+      s.z = (s.z >> 8) | (((px4 >> 16) & 255u) << 24);
+      s.w = (s.w >> 8) | ((px4 >> 24) << 24);
+      *reinterpret_cast<uint4*>(stack + p0) = s;
+    }
+  }
+}
+
 // Training rows out of the plane history: x[b] = the [OH,OW,4] uint8 state whose newest plane is history entry
 // seq[b] of agent[b] (planes seq-3 .. seq, oldest first) -- what the agent's queue held right after that push.
 __global__ __launch_bounds__(256) void gather_history_kernel(const uint8_t* __restrict__ ring, const int32_t* __restrict__ agents,

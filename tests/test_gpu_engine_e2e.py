@@ -250,3 +250,30 @@ def test_engine_on_raw_frames(tmp_path, monkeypatch, frontend):
             assert all(s.shape == (84, 84, 4) and int(s.max()) - int(s.min()) > 50 for s, _ in seen if s is not None)
     finally:
         srv.model.close()
+
+
+def test_engine_on_planes_with_the_frame_queue_on_the_device(tmp_path, monkeypatch):
+    """FRAME_SOURCE = 'planes', FRONTEND = 'device': agents ship their newest 84x84 plane (7,056 B per step), the frame queues
+    and the plane history live in HBM, rollouts name their states by (agent, plane)."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=6, PREDICTORS=2, TRAINERS=1, SYNTHETIC_EPISODE_LENGTH=40, TIME_MAX=5, DYNAMIC_SETTINGS=False,
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=11, NUM_ACTIONS=6, PREDICTION_BATCH_SIZE=32,
+                     FRAME_SOURCE='planes', FRONTEND='device').items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    srv = Server(max_agents=8)
+    try:
+        assert srv.device_frontend and srv.frame_shape == (84, 84, 1) and srv.transport.state_bytes == 84 * 84
+        before = srv.model.get_arena(0)
+        srv.main(max_seconds=5)
+        after = srv.model.get_arena(0)
+        assert srv.predictions_served > 100 and srv.training_step > 5
+        assert srv.model.get_global_step() == srv.training_step
+        assert np.all(np.isfinite(after)) and np.max(np.abs(after - before)) > 1e-5
+        assert all(not th.is_alive() for th in srv.trainers + srv.predictors)
+        seen = [srv.model.frame_state(a) for a in range(6)]
+        assert all(1 <= depth <= 4 for _, depth in seen) and any(depth == 4 for _, depth in seen)
+    finally:
+        srv.model.close()

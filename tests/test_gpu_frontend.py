@@ -209,6 +209,61 @@ def test_training_rows_from_the_plane_history(net):
         other.close()
 
 
+def test_ready_made_planes_keep_only_the_frame_queue_on_the_device(net):
+    """frames_config(..., 84, 84, 1): the "frames" are final planes (FRAME_SOURCE = 'planes', FRONTEND = 'device') -- no
+    gray / bytescale / resize, only the 4-deep queue and the plane history in HBM.  Queue contents, predictions and
+    training rows must equal what the host-side stacking of the same planes gives."""
+    from NetworkVP import Network
+    rng = np.random.default_rng(31)
+    n_agents, steps, hist = 6, 11, 12
+    other = Network("gpu:0", "test_planes_ref", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
+    try:
+        theta = net.get_arena(0)
+        for m in (net, other):
+            m.set_arena(0, theta)
+            m.set_arena(1, np.ones_like(theta))
+            m.learning_rate, m.beta = 3e-4, 0.01
+        net.frames_config(8, 84, 84, 1, history=hist)
+        ids = np.array([5, 1, 7, 0, 3, 6], np.int32)
+        queues = [ff.FrameQueue() for _ in range(n_agents)]
+        states = {}
+        for step in range(steps):
+            planes = rng.integers(0, 256, size=(n_agents, 84, 84, 1), dtype=np.uint8)
+            reset = np.zeros(n_agents, np.uint8)
+            if step == 0:
+                reset[:] = 1
+            if step == 4:
+                reset[3] = 1
+            seq = net.push_frames(planes, ids, reset)
+            assert seq.tolist() == [step] * n_agents
+            for k in range(n_agents):
+                if reset[k]:
+                    queues[k].clear()
+                queues[k].push(planes[k, :, :, 0])
+                state, depth = net.frame_state(ids[k])
+                want = queues[k].state_u8()
+                assert depth == len(queues[k].q) and (state is None) == (want is None)
+                if want is not None:
+                    assert np.array_equal(state, want)
+                    states[(int(ids[k]), step)] = want
+        ready = list(range(n_agents))
+        p, v = net.predict_frames(ids[ready])
+        p2, v2 = other.predict_p_and_v(np.stack([queues[k].state_u8() for k in ready]))
+        assert np.array_equal(p, p2) and np.array_equal(v, v2)
+        live = [(a, s) for (a, s) in states if steps - (s - 3) <= hist]
+        pick = [live[i] for i in rng.permutation(len(live))[:20]]
+        x = np.stack([states[k] for k in pick])
+        y = rng.uniform(-1, 1, len(pick))
+        act = np.eye(6, dtype=np.float32)[rng.integers(0, 6, len(pick))]
+        net.train_frames([a for a, _ in pick], [s for _, s in pick], y, act)
+        other.train(x, y, act, None, None, 0)
+        assert np.array_equal(net.get_arena(0), other.get_arena(0))
+        with pytest.raises(RuntimeError, match="ready-made"):
+            net.frames_config(8, 80, 84, 1)
+    finally:
+        other.close()
+
+
 def test_serve_frames_is_push_plus_predict_in_one_round_trip(net):
     """ga3c_net_serve_frames (the native raw-frame predictor loop's callback) against the two-call path."""
     import Transport as tp

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--linger-us", type=int, default=0)
     ap.add_argument("--linger-batch", type=int, default=0)
     ap.add_argument("--dynamic", action="store_true", help="ThreadDynamicAdjustment random walk every 2 s (soak test)")
-    ap.add_argument("--frames", choices=["planes", "rgb-host", "rgb-device"], default="planes",
+    ap.add_argument("--frames", choices=["planes", "planes-device", "rgb-host", "rgb-device"], default="planes",
                     help="frame source / where the reference's front-end runs (Config.FRAME_SOURCE, Config.FRONTEND)")
     args = ap.parse_args()
 
@@ -51,7 +51,9 @@ def main():
     Config.TRAIN_MODELS = not args.no_train
     Config.HOGWILD = bool(args.hogwild)
     Config.NATIVE_PREDICTOR = not args.python_predictor
-    if args.frames != "planes":
+    if args.frames == "planes-device":
+        Config.FRAME_SOURCE, Config.FRONTEND = "planes", "device"
+    elif args.frames != "planes":
         Config.FRAME_SOURCE, Config.FRONTEND = "rgb", args.frames.split("-")[1]
     Config.SAVE_MODELS = False
     Config.LOAD_CHECKPOINT = False

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--train-min-batch", type=int, default=127)
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--hogwild", action="store_true")
+    ap.add_argument("--frame-queue-on-device", action="store_true",
+                    help="FRAME_SOURCE = 'planes', FRONTEND = 'device': agents ship their newest plane, states stay in HBM")
     args = ap.parse_args()
     exe = build_tool()
 
@@ -52,6 +54,8 @@ def main():
     Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
     Config.TRAIN_MODELS = not args.no_train
     Config.HOGWILD = bool(args.hogwild)
+    if args.frame_queue_on_device:
+        Config.FRAME_SOURCE, Config.FRONTEND = "planes", "device"
     Config.SAVE_MODELS = False
     Config.LOAD_CHECKPOINT = False
     Config.RESULTS_FILENAME = "/tmp/engine_ceiling_results.txt"
@@ -88,9 +92,9 @@ def main():
         return
     dt = b["t"] - a["t"]
     pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
-    state_bytes = 84 * 84 * 4
+    state_bytes = 84 * 84 if args.frame_queue_on_device else 84 * 84 * 4
     print(json.dumps({
-        "agents": args.agents, "native_agents": True, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
+        "agents": args.agents, "native_agents": True, "frame_queue_on_device": bool(args.frame_queue_on_device), "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
         "hogwild": bool(args.hogwild), "window_s": round(dt, 2), "host_cores": os.cpu_count(),
         "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
         "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),

@@ -27,7 +27,10 @@ int main(int argc, char** argv) {
   if (ga3c_shm_attach(name, &shm) != 0) { fprintf(stderr, "attach: %s\n", ga3c_host_last_error()); return 1; }
   ga3c_shm_config cfg;
   ga3c_shm_get_config(shm, &cfg);
-  if (n > cfg.max_agents || cfg.rollout_row_bytes != 0) { fprintf(stderr, "segment does not fit (%d agents max)\n", cfg.max_agents); return 1; }
+  if (n > cfg.max_agents) { fprintf(stderr, "segment does not fit (%d agents max)\n", cfg.max_agents); return 1; }
+  // rollout_row_bytes == 16: the frame queue lives on the device (Config.FRONTEND = 'device'): the slot carries the newest
+  // frame / plane, requests carry flags, rollout rows name their state as (plane sequence number, agent id)
+  const bool device = cfg.rollout_row_bytes == 16;
   const size_t sb = (size_t)cfg.state_bytes;
   std::vector<unsigned char> pool(64 * sb);
   std::mt19937_64 rng(12345);
@@ -41,6 +44,8 @@ int main(int argc, char** argv) {
       std::vector<float> p(cfg.num_actions);
       std::vector<int> acts(cfg.train_rows);
       std::vector<int> frames(cfg.train_rows);
+      std::vector<long long> seqs(cfg.train_rows);
+      long long pushed = 0;
       float v = 0.f;
       int t = 0, k = id;
       unsigned char* slot = static_cast<unsigned char*>(ga3c_pq_state_ptr(shm, id));
@@ -50,7 +55,11 @@ int main(int argc, char** argv) {
         const auto c0 = std::chrono::steady_clock::now();
         memcpy(slot, &pool[(size_t)k * sb], sb);               // the emulator's next state
         const auto c1 = std::chrono::steady_clock::now();
-        if (ga3c_pq_submit(shm, id) != 0) break;
+        if (device) {
+          const uint32_t fl = (pushed == 0 ? GA3C_REQ_RESET : 0u) | (pushed < 3 ? GA3C_REQ_NO_PREDICT : 0u);
+          if (ga3c_pq_submit_flags(shm, id, fl) != 0) break;
+          ++pushed;
+        } else if (ga3c_pq_submit(shm, id) != 0) break;
         const auto c2 = std::chrono::steady_clock::now();
         int rc;
         while ((rc = ga3c_pq_wait(shm, id, p.data(), &v, 200)) != 0 && !stop.load(std::memory_order_relaxed))
@@ -62,10 +71,11 @@ int main(int argc, char** argv) {
           ns_submit.fetch_add((c2 - c1).count(), std::memory_order_relaxed);
           ns_wait.fetch_add((c3 - c2).count(), std::memory_order_relaxed);
         }
+        if (device && pushed < 4) continue;                     // the queue was still filling: no prediction came back
         float u = std::generate_canonical<float, 24>(r), c = 0.f;
         int a = cfg.num_actions - 1;
         for (int i = 0; i < cfg.num_actions; ++i) { c += p[i]; if (u < c) { a = i; break; } }
-        acts[t] = a; frames[t] = k;
+        acts[t] = a; frames[t] = k; seqs[t] = pushed - 1;
         ++mine;
         if (++t == cfg.train_rows - 1) {                        // TIME_MAX steps: ship the rollout
           if (train) {
@@ -76,7 +86,11 @@ int main(int argc, char** argv) {
             unsigned char* st = static_cast<unsigned char*>(ga3c_tq_states(shm, s));
             float* ret = ga3c_tq_returns(shm, s);
             int32_t* ac = ga3c_tq_actions(shm, s);
-            for (int i = 0; i < t; ++i) { memcpy(st + (size_t)i * sb, &pool[(size_t)frames[i] * sb], sb); ret[i] = 0.01f * (float)(i - 2); ac[i] = acts[i]; }
+            for (int i = 0; i < t; ++i) {
+              if (device) { memcpy(st + (size_t)i * 16, &seqs[i], 8); const int32_t me = id; memcpy(st + (size_t)i * 16 + 8, &me, 4); }
+              else memcpy(st + (size_t)i * sb, &pool[(size_t)frames[i] * sb], sb);
+              ret[i] = 0.01f * (float)(i - 2); ac[i] = acts[i];
+            }
             ga3c_tq_commit(shm, s, t);
             rollouts.fetch_add(1, std::memory_order_relaxed);
           }
