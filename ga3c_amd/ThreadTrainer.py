@@ -61,7 +61,7 @@ class ThreadTrainer(Thread):
         turn = getattr(self.server, "batch_lock", None) if holding else None
         # zero-copy batches are assembled by ONE native call (ga3c_tq_collect: the loop below, minus the interpreter --
         # at ~26 rollouts per 128-row batch the Python loop was 350 us under batch_lock, the trainers' ceiling)
-        native = holding and getattr(Config, "NATIVE_TRAINER", True) and hasattr(t, "collect")
+        native = (holding or on_device) and getattr(Config, "NATIVE_TRAINER", True) and hasattr(t, "collect")
         cstate = np.zeros(2, np.int32)                  # rows, slots of the batch in progress
         slot_stage = np.zeros(cap + 1, np.int32)
         while not self.exit_flag:
@@ -77,7 +77,7 @@ class ThreadTrainer(Thread):
                 while batch_size <= Config.TRAINING_MIN_BATCH_SIZE and not self.exit_flag:
                     if native and not spilled:
                         rc = t.collect(Config.TRAINING_MIN_BATCH_SIZE, Config.QUEUE_TIMEOUT_MS, 5, cstate, slot_stage, off_stage,
-                                       r_stage, a_stage)
+                                       r_stage, a_stage, seq_stage if on_device else None, agent_stage if on_device else None)
                         batch_size = int(cstate[0])
                         if rc == -4:
                             return                      # transport shut down

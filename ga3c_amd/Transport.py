@@ -142,12 +142,15 @@ class Transport:
     def rollout_row_offsets(self, slot, rows):
         return self._ro_off0 + slot * self._ro_stride + np.arange(rows, dtype=np.int64) * self.row_bytes
 
-    def collect(self, min_rows, timeout_ms, hold_timeout_ms, state, slots, offsets, returns, actions):
+    def collect(self, min_rows, timeout_ms, hold_timeout_ms, state, slots, offsets, returns, actions, seqs=None, agents=None):
         """ThreadTrainer's batch assembly in native code (ga3c_tq_collect).  `state` = int32[2]: rows and slots of the batch
-        in progress, kept across calls.  Returns 0 (batch complete), -3 (timeout), -4 (closed) or 1 (starved: give slots back)."""
+        in progress, kept across calls.  Returns 0 (batch complete), -3 (timeout), -4 (closed) or 1 (starved: give slots back).
+        seqs / agents: the rows name states kept on the device; they are decoded there and the slots released at once."""
         return nat.check_host(self._lib.ga3c_tq_collect(self._h, min_rows, timeout_ms, hold_timeout_ms, state.ctypes.data,
                                                         state.ctypes.data + 4, slots.ctypes.data, offsets.ctypes.data,
-                                                        returns.ctypes.data, actions.ctypes.data, len(returns), len(slots)),
+                                                        returns.ctypes.data, actions.ctypes.data, len(returns), len(slots),
+                                                        seqs.ctypes.data if seqs is not None else None,
+                                                        agents.ctypes.data if agents is not None else None),
                               "ga3c_tq_collect")
 
     def release_many(self, slots, n):

@@ -131,7 +131,7 @@ HOST_SIGNATURES = {
     "ga3c_tq_rows": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_tq_release": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_tq_collect": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "ga3c_tq_release_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "ga3c_tq_ready_count": (C.c_int, [C.c_void_p]),
     "ga3c_tq_free_count": (C.c_int, [C.c_void_p]),

@@ -884,11 +884,14 @@ int ga3c_tq_pop(ga3c_shm* shm, int32_t timeout_ms) {
 
 int ga3c_tq_collect(ga3c_shm* shm, int32_t min_rows, int32_t timeout_ms, int32_t hold_timeout_ms, int32_t* rows,
                     int32_t* n_slots, int32_t* slots, int64_t* row_offsets, float* returns, int32_t* actions,
-                    int32_t cap_rows, int32_t cap_slots) {
+                    int32_t cap_rows, int32_t cap_slots, int64_t* row_seq, int32_t* row_agent) {
   if (!shm || !rows || !n_slots || !slots || !row_offsets || !returns || !actions) return fail(GA3C_H_EINVAL, "null argument");
   Header* h = shm->hdr();
   if (*rows < 0 || *n_slots < 0 || min_rows < 0) return fail(GA3C_H_EINVAL, "bad batch state");
   const int64_t row_bytes = h->cfg.rollout_row_bytes ? h->cfg.rollout_row_bytes : h->cfg.state_bytes;
+  const bool names = row_seq != nullptr || row_agent != nullptr;     // rows only NAME states kept on the device
+  if (names && (!row_seq || !row_agent || h->cfg.rollout_row_bytes != 16))
+    return fail(GA3C_H_EINVAL, "row names need both arrays and 16-byte rollout rows");
   while (*rows <= min_rows) {
     if (*rows + h->cfg.train_rows > cap_rows || *n_slots >= cap_slots) return fail(GA3C_H_EINVAL, "batch arrays too small");
     // the caller keeps the slots until the GPU has read them: if the agents have none left and nothing is queued, it
@@ -904,8 +907,17 @@ int ga3c_tq_collect(ga3c_shm* shm, int32_t min_rows, int32_t timeout_ms, int32_t
     for (int32_t i = 0; i < n; ++i) row_offsets[*rows + i] = off0 + i * row_bytes;
     memcpy(returns + *rows, ro + h->ro_returns_off, (size_t)n * sizeof(float));
     memcpy(actions + *rows, ro + h->ro_actions_off, (size_t)n * sizeof(int32_t));
-    slots[*n_slots] = (int32_t)slot;
-    *n_slots += 1;
+    if (names) {                                             // (plane sequence number i64, agent id i32) per row; the slot is done
+      for (int32_t i = 0; i < n; ++i) {
+        memcpy(&row_seq[*rows + i], ro + i * row_bytes, 8);
+        memcpy(&row_agent[*rows + i], ro + i * row_bytes + 8, 4);
+      }
+      const int rr = ga3c_tq_release(shm, (int32_t)slot);
+      if (rr != GA3C_H_OK) return rr;
+    } else {
+      slots[*n_slots] = (int32_t)slot;
+      *n_slots += 1;
+    }
     *rows += n;
   }
   return GA3C_H_OK;

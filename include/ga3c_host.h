@@ -147,9 +147,11 @@ int ga3c_tq_release(ga3c_shm* shm, int32_t slot);
  * first rollout and hold_timeout_ms once slots are held.  GA3C_H_ESTARVED: slots are held, none is free and none is queued
  * -- the agents are blocked on the caller, which must give slots back before asking again. */
 #define GA3C_H_ESTARVED 1
+/* row_seq / row_agent (both or neither; 16-byte rollout rows only): the rows NAME states kept on the device -- plane sequence
+ * number and agent id are decoded into these arrays and every slot is released at once (nothing is held, *n_slots stays 0). */
 int ga3c_tq_collect(ga3c_shm* shm, int32_t min_rows, int32_t timeout_ms, int32_t hold_timeout_ms, int32_t* rows,
                     int32_t* n_slots, int32_t* slots, int64_t* row_offsets, float* returns, int32_t* actions,
-                    int32_t cap_rows, int32_t cap_slots);
+                    int32_t cap_rows, int32_t cap_slots, int64_t* row_seq, int32_t* row_agent);
 int ga3c_tq_release_many(ga3c_shm* shm, const int32_t* slots, int32_t n);
 int ga3c_tq_ready_count(ga3c_shm* shm);
 int ga3c_tq_free_count(ga3c_shm* shm);    /* slots no producer and no consumer holds; 0 = producers are blocked */
