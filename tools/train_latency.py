@@ -1,0 +1,52 @@
+"""Latency of one synchronous train call through the C ABI (development aid): rows gathered out of the registered transport
+segment (the zero-copy trainer path) against the same batch resident in HBM.
+
+    python tools/train_latency.py [batch ...]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import ga3c_amd, Transport as tp
+from NetworkVP import Network
+import _native as nat
+
+batches = [int(b) for b in sys.argv[1:]] or [32, 128, 130]
+t = tp.Transport.create(tp.unique_name("tlat"), 160, 6, 84 * 84 * 4, 8, 6)
+net = Network("gpu:0", "tlat", 6, (84, 84, 4), max_batch=160, predict_lanes=2)
+net.register_transport(t)
+rng = np.random.default_rng(0)
+t.agent_states[:] = rng.integers(0, 256, size=(160, 84 * 84 * 4), dtype=np.uint8)
+net.learning_rate, net.beta = 3e-4, 0.01
+for n in batches:
+    offs = t.state_offsets(np.arange(n, dtype=np.uint32))
+    y = rng.uniform(-1, 1, n).astype(np.float32)
+    a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, n)]
+    for _ in range(30):
+        net.train_offsets(offs, y, a)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        net.train_offsets(offs, y, a)
+    call = (time.perf_counter() - t0) / 300 * 1e6
+    xk = np.ascontiguousarray(t.agent_states[:n]).reshape(n, 84, 84, 4)
+    nat.check(net._lib.ga3c_net_upload_u8(net._h, nat.ptr(xk, nat.u8p), nat.ptr(y), nat.ptr(a), n))
+    ms = nat.C.c_float()
+    nat.check(net._lib.ga3c_net_time_resident(net._h, 1, n, 300, 3e-4, 0.01, nat.C.byref(ms)))
+    print("batch %3d: synchronous train_offsets call %6.1f us; resident, pipelined %5.1f us per step" % (n, call, ms.value / 300 * 1e3))
+net.unregister_transport()
+# rows named by (agent, plane) out of the device-side plane history (frame queue on the device)
+net.frames_config(160, 84, 84, 1, history=16)
+ids = np.arange(160, dtype=np.int32)
+for step in range(8):
+    net.push_frames(rng.integers(0, 256, size=(160, 84, 84, 1), dtype=np.uint8), ids, np.full(160, step == 0, np.uint8))
+for n in batches:
+    ag = ids[:n].copy()
+    sq = np.full(n, 7, np.int64)
+    y = rng.uniform(-1, 1, n).astype(np.float32)
+    a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, n)]
+    for _ in range(30):
+        net.train_frames(ag, sq, y, a)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        net.train_frames(ag, sq, y, a)
+    print("batch %3d: synchronous train_frames call %6.1f us" % (n, (time.perf_counter() - t0) / 300 * 1e6))
+t.shutdown(); t.close(); net.close()
