@@ -52,8 +52,10 @@ def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2, trai
     Config.PRINT_STATS_FREQUENCY = 10 ** 9
     Config.RESULTS_FILENAME = os.devnull
     Config.NUM_ACTIONS = A
-    Config.FRAME_SOURCE, Config.FRONTEND = {"planes": ("planes", "host"), "planes-device": ("planes", "device")}.get(
-        frames, ("rgb", frames.split("-")[1]))
+    if frames in ("planes", "planes-device"):
+        Config.FRAME_SOURCE, Config.FRONTEND = "planes", ("device" if frames == "planes-device" else "host")
+    else:
+        Config.FRAME_SOURCE, Config.FRONTEND = "rgb", frames.split("-")[1]
     real_stdout = sys.stdout
     sys.stdout = sys.stderr
     try:
