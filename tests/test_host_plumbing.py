@@ -298,6 +298,42 @@ def test_zero_copy_trainer_spills_when_the_agents_run_out_of_slots(mods, native)
         t.close()
 
 
+def test_collect_decodes_rows_that_name_device_states_and_frees_their_slots(mods):
+    """16-byte rollout rows = (plane sequence number i64, agent id i32): ga3c_tq_collect hands them back decoded, releases
+    every slot at once (nothing is held, so it can never report starvation) and keeps the batch rule of ThreadTrainer.py:48."""
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_names"), 4, 4, 7056, 3, 6, 16)
+    try:
+        want_seq, want_agent = [], []
+        for k in range(3):
+            slot = t.acquire(100)
+            states, returns, actions = t.rollout_views(slot)
+            for i in range(4):
+                states[i, :8].view(np.int64)[0] = 1000 * k + i
+                states[i, 8:12].view(np.int32)[0] = k
+                returns[i], actions[i] = 0.5 * i, i % 4
+                want_seq.append(1000 * k + i)
+                want_agent.append(k)
+            t.commit(slot, 4)
+        state = np.zeros(2, np.int32)
+        cap = 16
+        slots, offs = np.zeros(cap, np.int32), np.zeros(cap, np.int64)
+        r, a = np.zeros(cap, np.float32), np.zeros(cap, np.int32)
+        seqs, agents = np.zeros(cap, np.int64), np.zeros(cap, np.int32)
+        assert t.collect(8, 100, 5, state, slots, offs, r, a, seqs, agents) == 0          # 3 rollouts x 4 rows > 8
+        assert state.tolist() == [12, 0]
+        assert seqs[:12].tolist() == want_seq and agents[:12].tolist() == want_agent
+        assert r[:12].tolist() == [0.0, 0.5, 1.0, 1.5] * 3 and a[:12].tolist() == [0, 1, 2, 3] * 3
+        assert t.free_count() == 3 and t.ready_count() == 0
+        state[:] = 0
+        assert t.collect(8, 20, 5, state, slots, offs, r, a, seqs, agents) == tp.TIMEOUT and state.tolist() == [0, 0]
+        with pytest.raises(RuntimeError):
+            t.collect(8, 20, 5, state, slots, offs, r, a, seqs, None)                     # both arrays or neither
+    finally:
+        t.shutdown()
+        t.close()
+
+
 def test_transport_rejects_double_submit_and_times_out(mods):
     nat, tp, Config = mods
     t = tp.Transport.create(tp.unique_name("t_misc"), 4, 6, 32, 2, 3)
