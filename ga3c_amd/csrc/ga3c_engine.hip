@@ -290,6 +290,7 @@ int launch_dense1_heads(ga3c_net* net, const Fwd& f, const float* pk, const Head
   return GA3C_OK;
 }
 
+constexpr int HEADS_WAVES = 1;   // samples (waves) per heads workgroup
 // ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
 int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, bool train,
                    const TrainLane* tl, float beta, float* out_p = nullptr, float* out_v = nullptr) {
@@ -327,7 +328,7 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
     return GA3C_OK;
   }
   CHK(launch_dense1_fwd(net, f.n2, net->theta_pk[idx], f.part, B, ks, st, nullptr, nullptr));
-#define HEADS(T, AM) hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + 3) / 4), dim3(256), 0, st, h)
+#define HEADS(T, AM) hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + HEADS_WAVES - 1) / HEADS_WAVES), dim3(64 * HEADS_WAVES), 0, st, h)
   if (A <= 8) { if (train) HEADS(true, 8); else HEADS(false, 8); }
   else if (A <= 24) { if (train) HEADS(true, 24); else HEADS(false, 24); }
   else { if (train) HEADS(true, 64); else HEADS(false, 64); }
@@ -1847,9 +1848,11 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       h.bd = th + OFF_BD; h.wv = th + OFF_WV; h.bv = th + OFF_BV; h.wp = th + OFF_WP; h.bp = th + off_bp(net->A);
       h.d1 = t.f.d1; h.z = t.f.z; h.p = t.f.p; h.v = t.f.v;
       h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
-      if (net->A <= 8) TL((heads_kernel<false, 8>), dim3((B + 3) / 4), h);
-      else if (net->A <= 24) TL((heads_kernel<false, 24>), dim3((B + 3) / 4), h);
-      else TL((heads_kernel<false, 64>), dim3((B + 3) / 4), h);
+#define HEADS_T(AM) hipExtLaunchKernelGGL((heads_kernel<false, AM>), dim3((B + HEADS_WAVES - 1) / HEADS_WAVES), dim3(64 * HEADS_WAVES), 0, t.st, t.ev0, t.ev1, 0, h)
+      if (net->A <= 8) HEADS_T(8);
+      else if (net->A <= 24) HEADS_T(24);
+      else HEADS_T(64);
+#undef HEADS_T
     } else if (k == "slab_reduce") {
       const int nch1 = B * 7 < 512 ? B * 7 : 512, nch2 = B < 256 ? B : 256;
       SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64, OFF_W1, OFF_B1};

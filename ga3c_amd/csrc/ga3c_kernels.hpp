@@ -832,7 +832,7 @@ __device__ __forceinline__ void heads_rows(const HeadArgs& h, const int (&rows)[
 
 template <bool TRAIN, int AMAX>
 __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // one wave per sample; 1..4 waves per workgroup
   if (b >= h.B) return;   // wave-uniform
   const int rows[1] = {b};
   heads_rows<TRAIN, AMAX, 1>(h, rows, threadIdx.x & 63);
