@@ -9,9 +9,11 @@ frames, NetworkVP) on N MI355X of one node.
 A step is one pass of the hot path over one batch that is already resident in HBM:
   predict leg (the headline `value`): one ThreadPredictor batch (BASELINE.json configs[1]:
       batch = 128 states) through the HIP NetworkVP forward -> p, v.  The K steps are dealt round-robin to
-      NP = 2 prediction lanes, i.e. the reference's default Config.PREDICTORS = 2 predictor threads
-      (Config.py:57, README.md:28-32 "NP: 2"), each lane with its own HIP stream and workspace exactly as
-      ThreadPredictor uses them; the single-lane figure is reported beside it under "predict_lanes";
+      NP prediction lanes = predictor threads, each lane with its own HIP stream and workspace exactly as
+      ThreadPredictor uses them.  NP = 4 (--predictors): the reference starts with Config.PREDICTORS = 2
+      (Config.py:57, README.md:28-32 "NP: 2") and walks NP at run time (ThreadDynamicAdjustment); on the MI355X
+      four lanes on eight hardware queues are the best setting (profiles/README.md).  The 1-, 2- and 3-lane
+      figures of the same K steps are reported beside it under "predict_lanes";
   train leg (reported under "train"): one ThreadTrainer batch (configs[2]: 128 rows) through forward,
       loss, backward, RCCL all-reduce of the gradient arena when N > 1, RMSProp.
 Per-GPU work is fixed as N grows (weak scaling); predictions need no collective.
@@ -27,6 +29,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this stack
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # one hardware queue per lane (ga3c_amd/__init__.py); before HIP initialises
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -129,7 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--actions", type=int, default=6)
-    ap.add_argument("--predictors", type=int, default=2, help="prediction lanes the K predict steps are dealt to (Config.PREDICTORS)")
+    ap.add_argument("--predictors", type=int, default=4, help="prediction lanes the K predict steps are dealt to (predictor threads)")
     ap.add_argument("--no-lane-sweep", action="store_true",
                     help="skip the extra 1- and 3-lane legs (use with --predictors 1 under rocprofv3 so that kernels never overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length; 0 disables it")
@@ -169,7 +172,7 @@ def main():
     B, A, K, W = args.batch, args.actions, args.steps, args.warmup
     Config.PREDICTION_BATCH_SIZE = B
     NP = max(1, args.predictors)
-    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=max(NP, 3))
+    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=max(NP, 4))
     lib, h = net._lib, net._h
 
     import DataParallel
@@ -247,7 +250,11 @@ def main():
         nat.check(lib.ga3c_net_time_predict_lanes(h, B, W, NP, nat.C.byref(ev_ms)), "warmup")
     pred_s, _ = timed(0, K, lanes=NP, tag="predict")
     one_s, pred_ev_ms = timed(0, K)
-    three_s = pred_s if args.no_lane_sweep else timed(0, K, lanes=3)[0]
+    sweep = {}
+    if not args.no_lane_sweep:
+        for nl in (2, 3, 4):
+            if nl != NP:
+                sweep[nl] = timed(0, K, lanes=nl)[0]
     dp_guard = None
     if world > 1:
         # the collective legs below have never run with N > 1 on hardware in this build's development (one-GPU box): if a
@@ -301,8 +308,11 @@ def main():
                                    "predictor batch=%d, NP=%d predictor lanes per GPU, A=%d (BASELINE configs[1])" % (B, NP, A),
                        "global_batch": world * B, "parallelism": "dp%d" % world,
                        "inputs": "resident in HBM (f32 NHWC), outputs p,v left in HBM"},
-            "predict_lanes": {"1": world * K * B / one_s, str(NP): pps, "3": world * K * B / three_s,
-                              "unit": "predictions/s", "note": "same K steps dealt to 1 / NP / 3 prediction lanes"},
+            "predict_lanes": dict({"1": world * K * B / one_s, str(NP): pps},
+                                  **{str(nl): world * K * B / s_ for nl, s_ in sweep.items()},
+                                  unit="predictions/s", hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+                                  note="same K steps dealt to 1 .. 4 prediction lanes; `value` is the NP-lane figure "
+                                       "(the reference's default NP = 2 is the \"2\" entry)"),
             "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
                       "ms_per_step": train_s / K * 1e3 if train_s else None, "rows_per_step": world * B,
                       "trained_samples_per_sec": world * K * B / train_s if train_s else None,
