@@ -416,11 +416,11 @@ def main():
 
     # ---- Hogwild trainers: the reference's default NT = 2 trainer threads update shared weights unlocked (Server.py:132-134)
     if rank == 0 and world == 1:
-        hog = Network("gpu:%d" % local_rank, "bench_hogwild", A, (84, 84, 4), max_batch=B, predict_lanes=1, train_lanes=2)
+        hog = Network("gpu:%d" % local_rank, "bench_hogwild", A, (84, 84, 4), max_batch=B, predict_lanes=1, train_lanes=4)
         nat.check(hog._lib.ga3c_net_upload(hog._h, nat.ptr(x), nat.ptr(y_r), nat.ptr(act), B), "upload")
         ms = nat.C.c_float()
         res = {}
-        for nl in (1, 2):
+        for nl in (1, 2, 4):
             nat.check(hog._lib.ga3c_net_time_train_lanes(hog._h, B, max(W, 1), nl, lr, beta, nat.C.byref(ms)), "warmup")
             torch.cuda.synchronize()
             nat.check(hog._lib.ga3c_net_time_train_lanes(hog._h, B, K, nl, lr, beta, nat.C.byref(ms)), "time_train_lanes")
