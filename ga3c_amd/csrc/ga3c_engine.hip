@@ -190,6 +190,10 @@ struct ga3c_net {
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
   bool d1_heads = false;               // GA3C_D1_HEADS=1: dense1 forward + heads in one launch, last-arriving workgroup of a row tile.
                                        // Measured: 29 us against 5.7 + 5.8 us as two launches (profiles/README.md) -- kept for the record, off
+  int d1f_frag_lanes = 3;              // prediction steps of >= 64 rows use the register-fragment dense1 (no LDS: it shares a CU
+                                       // with another lane's conv stack, which the 148 KB tile kernel cannot) while at least
+                                       // this many prediction calls are in flight (GA3C_D1F_FRAG_LANES; 0 = never).  Same bits.
+  std::atomic<int> predict_inflight{0};
   bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
   bool graphs = false;                 // GA3C_GRAPHS=1: prediction steps replayed as hipGraphs.  Off by default: on ROCm 7.2 a
@@ -249,12 +253,12 @@ bool is_pinned(const void* p) {
 // dense1 forward: the LDS-tiled kernel while its grid is one round of workgroups (one workgroup per CU: its LDS image
 // is 120-145 KB), the register-fragment kernel beyond
 int launch_dense1_fwd(ga3c_net* net, const float* flat, const float* pk, float* part, int B, int ks, hipStream_t st,
-                      hipEvent_t e0, hipEvent_t e1) {
+                      hipEvent_t e0, hipEvent_t e1, bool prefer_frag = false) {
   const int max_steps = (KSTEPS_DENSE + ks - 1) / ks;
   const int mt = B <= 128 ? 1 : 2;
   const size_t lds = (size_t)d1f_lds_floats(mt, max_steps) * sizeof(float);
   const int tile_blocks = dense1_fwd_blocks(B, ks, mt);
-  if (net->d1f_tile && max_steps <= 16 && lds <= 160 * 1024 && tile_blocks <= 256) {
+  if (net->d1f_tile && !prefer_frag && max_steps <= 16 && lds <= 160 * 1024 && tile_blocks <= 256) {
     if (mt == 1)
       hipExtLaunchKernelGGL(dense1_fwd_tile_kernel<1>, dim3(tile_blocks), dim3(512), lds, st, e0, e1, 0, flat, pk, part, B, ks, max_steps);
     else
@@ -327,7 +331,10 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
     CHK(launch_dense1_heads(net, f, net->theta_pk[idx], h, B, ks, st, train, nullptr, nullptr));
     return GA3C_OK;
   }
-  CHK(launch_dense1_fwd(net, f.n2, net->theta_pk[idx], f.part, B, ks, st, nullptr, nullptr));
+  // several prediction lanes at work: the fragment kernel (no LDS) runs beside the other lanes' conv stacks
+  const bool frag = !train && !net->graphs && net->d1f_frag_lanes > 0 && B >= 64 &&
+                    net->predict_inflight.load(std::memory_order_relaxed) >= net->d1f_frag_lanes;
+  CHK(launch_dense1_fwd(net, f.n2, net->theta_pk[idx], f.part, B, ks, st, nullptr, nullptr, frag));
 #define HEADS(T, AM) hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + HEADS_WAVES - 1) / HEADS_WAVES), dim3(64 * HEADS_WAVES), 0, st, h)
   if (A <= 8) { if (train) HEADS(true, 8); else HEADS(false, 8); }
   else if (A <= 24) { if (train) HEADS(true, 24); else HEADS(false, 24); }
@@ -781,6 +788,14 @@ int launch_frames(ga3c_net* net, const uint8_t* rgb_dev, const int32_t* agents, 
   return GA3C_OK;
 }
 
+struct PredictInFlight {   // one per prediction call / lane driver: how many lanes are at work right now
+  ga3c_net* n;
+  explicit PredictInFlight(ga3c_net* net) : n(net) { n->predict_inflight.fetch_add(1, std::memory_order_relaxed); }
+  ~PredictInFlight() { n->predict_inflight.fetch_sub(1, std::memory_order_relaxed); }
+  PredictInFlight(const PredictInFlight&) = delete;
+  PredictInFlight& operator=(const PredictInFlight&) = delete;
+};
+
 Lane* take_lane(ga3c_net* net) {
   const unsigned start = net->rr.fetch_add(1);
   for (size_t k = 0; k < net->lanes.size(); ++k) {
@@ -811,6 +826,7 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
   if (!net || !x || !p || !v) return fail(GA3C_EINVAL, "null argument");
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
+  PredictInFlight inflight(net);
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   if (u8) {
@@ -949,6 +965,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_D1F_FRAG_LANES")) net->d1f_frag_lanes = atoi(e);
   if (const char* e = getenv("GA3C_D1_HEADS")) net->d1_heads = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
@@ -1265,6 +1282,7 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
                             float* z) {
   if (!net || !offsets || !p || !v) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
+  PredictInFlight inflight(net);
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   CHK(stage_offsets(net, offsets, batch, u8 != 0, L->h_off));
@@ -1441,6 +1459,7 @@ int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, flo
                     agents[i], f.filled[agents[i]], CIN);
     }
   }
+  PredictInFlight inflight(net);
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   for (int i = 0; i < n; ++i) L->h_off[i] = (int64_t)agents[i] * XS;
@@ -1455,6 +1474,7 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
   if (n < 1 || n > f.maxA || n > net->maxB) return fail(GA3C_EINVAL, "frames: %d requests outside [1,%d]", n, f.maxA < net->maxB ? f.maxA : net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
+  PredictInFlight inflight(net);
   Lane* L = take_lane(net);
   std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
   // per-call argument arrays, carved out of the lane's (otherwise idle) pinned input staging and read by the kernels in place
@@ -1706,6 +1726,7 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   auto drive = [&](int l) {
     if (hipSetDevice(net->cfg.device) != hipSuccess) { rcs[l] = GA3C_EHIP; return; }
     Lane* L = net->lanes[l];
+    PredictInFlight inflight(net);
     for (int i = l; i < iters; i += nlanes) {
       const int rc = lane_step(net, *L, idx, batch, STEP_RESIDENT, nullptr, nullptr);
       if (rc != GA3C_OK) { rcs[l] = rc; errs[l] = g_err; return; }

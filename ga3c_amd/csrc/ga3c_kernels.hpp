@@ -591,9 +591,11 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
   }
   const float* w0p = pk + (size_t)(n0 + r) * 16 + 4 * g;
   const float* w1p = w0p + 16 * 16;
-  f32x4 acc[MT][2];
+  // two accumulators per output tile (k steps t = 0, 2 | 1, 3), added at the end: the summation order of
+  // dense1_fwd_tile_kernel, so that the two kernels give the same bits and the engine may pick either per step
+  f32x4 acc[MT][2][2];
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) acc[mi][0] = acc[mi][1] = zero4();
+  for (int mi = 0; mi < MT; ++mi) acc[mi][0][0] = acc[mi][0][1] = acc[mi][1][0] = acc[mi][1][1] = zero4();
   // slice ks of ks_total: the 242 K steps are cut as evenly as integers allow (steps_per_slice < 0), so that the slice
   // count can be picked to fill whole rounds of workgroups on the 256 CUs rather than to divide 242
   const int s0 = steps_per_slice > 0 ? ks * steps_per_slice : (ks * KSTEPS_DENSE) / ks_total;
@@ -615,8 +617,8 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
-        acc[mi][0] = mfma(a[mi][t], w0[t], acc[mi][0]);
-        acc[mi][1] = mfma(a[mi][t], w1[t], acc[mi][1]);
+        acc[mi][0][t & 1] = mfma(a[mi][t], w0[t], acc[mi][0][t & 1]);
+        acc[mi][1][t & 1] = mfma(a[mi][t], w1[t], acc[mi][1][t & 1]);
       }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) a[mi] = na[mi];
@@ -629,8 +631,8 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
     for (int q = 0; q < 4; ++q) {
       const int mr = m0 + mi * 16 + 4 * g + q;
       if (mr < B) {
-        out[(size_t)mr * HID] = acc[mi][0][q];
-        out[(size_t)mr * HID + 16] = acc[mi][1][q];
+        out[(size_t)mr * HID] = acc[mi][0][0][q] + acc[mi][0][1][q];
+        out[(size_t)mr * HID + 16] = acc[mi][1][0][q] + acc[mi][1][1][q];
       }
     }
 }

@@ -330,6 +330,27 @@ def test_dense1_heads_single_launch_same_bits(nets, monkeypatch):
         net.close()
 
 
+def test_dense1_fragment_and_tile_kernels_give_the_same_bits(nets, monkeypatch):
+    """The engine picks dense1's register-fragment kernel (no LDS) for prediction steps while three or more lanes are at work,
+    the LDS-tiled one otherwise: the choice depends on timing, so the two must agree bit for bit (same split-K slices, same
+    two-accumulator summation order)."""
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    ref = nets(6)
+    monkeypatch.setenv("GA3C_D1F_TILE", "0")
+    net = Network("gpu:0", "test_d1frag", 6, (84, 84, 4), max_batch=160, predict_lanes=2)
+    monkeypatch.delenv("GA3C_D1F_TILE")
+    try:
+        for n in (net, ref):
+            n.set_arena(0, _flat(o.init_params(6), 6))
+        for B in (1, 17, 64, 100, 128, 131, 160):
+            _, x, a, y = _batch(B, 6, 900 + B)
+            got, want = net.predict_p_v_logits(x), ref.predict_p_v_logits(x)
+            assert all(np.array_equal(g, w) for g, w in zip(got, want)), B
+    finally:
+        net.close()
+
+
 def test_batch_row_permutation_properties(nets):
     """Full predictor batch (128, BASELINE configs[1]): rows are independent, so permuting the batch permutes the
     outputs bit for bit; the sum-reduced gradient is permutation invariant up to f32 summation order."""
