@@ -107,7 +107,9 @@ class Network:
         cfg.log_epsilon = Config.LOG_EPSILON
         cfg.min_policy = Config.MIN_POLICY
         cfg.grad_clip_norm = Config.GRAD_CLIP_NORM
-        cfg.predict_lanes = int(predict_lanes or max(1, Config.PREDICTORS))
+        # a lane = stream + workspace of one prediction in flight; ThreadDynamicAdjustment may start more predictor threads than
+        # Config.PREDICTORS, and four lanes are what the chip runs best (profiles/README.md): threads beyond the lanes share them
+        cfg.predict_lanes = int(predict_lanes or max(4, Config.PREDICTORS))
         if train_lanes is None:
             train_lanes = max(1, Config.TRAINERS) if Config.HOGWILD else 1
         cfg.train_lanes = int(train_lanes)
