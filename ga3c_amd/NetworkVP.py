@@ -107,9 +107,10 @@ class Network:
         cfg.log_epsilon = Config.LOG_EPSILON
         cfg.min_policy = Config.MIN_POLICY
         cfg.grad_clip_norm = Config.GRAD_CLIP_NORM
-        # a lane = stream + workspace of one prediction in flight; ThreadDynamicAdjustment may start more predictor threads than
-        # Config.PREDICTORS, and four lanes are what the chip runs best (profiles/README.md): threads beyond the lanes share them
-        cfg.predict_lanes = int(predict_lanes or max(4, Config.PREDICTORS))
+        # a lane = stream + workspace of one prediction in flight; predictor threads beyond the lanes share them.  More lanes
+        # than predictor threads cost the ENGINE throughput (2 predictors on 4 lanes: 310 k predictions/s against 353 k on 2,
+        # profiles/README.md), so the default is one per configured predictor; GA3C_PREDICT_LANES overrides it
+        cfg.predict_lanes = int(predict_lanes or os.environ.get("GA3C_PREDICT_LANES") or max(1, Config.PREDICTORS))
         if train_lanes is None:
             train_lanes = max(1, Config.TRAINERS) if Config.HOGWILD else 1
         cfg.train_lanes = int(train_lanes)
