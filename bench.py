@@ -29,7 +29,9 @@ import time
 import numpy as np
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this stack
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # one hardware queue per lane (ga3c_amd/__init__.py); before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # a hardware queue per lane for the resident legs (4 lanes: 7.5 -> 9.3 M
+                                                           # predictions/s); must be set before HIP initialises.  The engine legs
+                                                           # (2 predictor threads) are indifferent to it (profiles/README.md)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):

@@ -11,12 +11,10 @@ flat imports work from anywhere; there is exactly one copy of each module.
 import os
 import sys
 
-# Every prediction lane, the train lane(s), the frame queues and the gradient exchange have HIP streams of their own, and
-# the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): two lanes that land on one queue
-# run back to back.  Measured on an MI355X, 4 prediction lanes at batch 128: 7.5 M predictions/s on 4 queues, 9.0 M on 8
-# (profiles/README.md).  Read by the HIP runtime when it initialises, so this must come before the first HIP call; a value
-# set by the user wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP streams (prediction lanes, train lanes, frame queues, gradient exchange) are multiplexed onto GPU_MAX_HW_QUEUES hardware
+# queues, 4 unless the environment says otherwise.  On resident batches a queue per lane pays (4 lanes: 7.5 -> 9.3 M
+# predictions/s with 8 queues; bench.py sets it), but the whole engine with 4 predictor threads fell from 344 k to 203 k
+# predictions/s on 8 queues (profiles/README.md): the package leaves the runtime's default alone.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 if _HERE not in sys.path:

@@ -7,10 +7,6 @@ import os
 
 import numpy as np
 
-# one hardware queue per lane (see ga3c_amd/__init__.py; repeated here because `cd ga3c_amd && sh _train.sh` imports the
-# flat modules without the package): read by the HIP runtime when it initialises, i.e. at the first call into the library
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "libga3c_hip.so")
 HOST_LIB = os.path.join(_HERE, "libga3c_host.so")
