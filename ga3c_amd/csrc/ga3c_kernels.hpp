@@ -600,29 +600,34 @@ __global__ __launch_bounds__(256) void dense1_fwd_kernel(const float* __restrict
   // count can be picked to fill whole rounds of workgroups on the 256 CUs rather than to divide 242
   const int s0 = steps_per_slice > 0 ? ks * steps_per_slice : (ks * KSTEPS_DENSE) / ks_total;
   const int s1 = steps_per_slice > 0 ? s0 + steps_per_slice : ((ks + 1) * KSTEPS_DENSE) / ks_total;
-  f32x4 a[MT], w0 = ld4(w0p + (size_t)s0 * HID * 16), w1 = ld4(w1p + (size_t)s0 * HID * 16);
+  // D steps of operands in flight (a ring of register slots, the loop unrolled by D so that slot numbers are compile-time):
+  // a step is a dependent L2 round trip, and one step of prefetch left the wave waiting on most of it
+  constexpr int D = MT == 1 ? 4 : 2;
+  f32x4 a[D][MT], w0[D], w1[D];
+  auto fetch = [&](int slot, int s) {
+    if (s < s1) {
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) a[mi] = v[mi] ? ld4(ap[mi] + 16 * s0) : zero4();
-  for (int s = s0; s < s1; ++s) {
-    f32x4 na[MT], nw0 = zero4(), nw1 = zero4();
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) na[mi] = zero4();
-    if (s + 1 < s1) {
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) na[mi] = v[mi] ? ld4(ap[mi] + 16 * (s + 1)) : zero4();
-      nw0 = ld4(w0p + (size_t)(s + 1) * HID * 16);
-      nw1 = ld4(w1p + (size_t)(s + 1) * HID * 16);
+      for (int mi = 0; mi < MT; ++mi) a[slot][mi] = v[mi] ? ld4(ap[mi] + 16 * s) : zero4();
+      w0[slot] = ld4(w0p + (size_t)s * HID * 16);
+      w1[slot] = ld4(w1p + (size_t)s * HID * 16);
     }
+  };
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+  for (int d = 0; d < D; ++d) fetch(d, s0 + d);
+  for (int s = s0; s < s1; s += D) {
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        acc[mi][0][t & 1] = mfma(a[mi][t], w0[t], acc[mi][0][t & 1]);
-        acc[mi][1][t & 1] = mfma(a[mi][t], w1[t], acc[mi][1][t & 1]);
+    for (int d = 0; d < D; ++d) {
+      if (s + d < s1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            acc[mi][0][t & 1] = mfma(a[d][mi][t], w0[d][t], acc[mi][0][t & 1]);
+            acc[mi][1][t & 1] = mfma(a[d][mi][t], w1[d][t], acc[mi][1][t & 1]);
+          }
+        fetch(d, s + d + D);
       }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) a[mi] = na[mi];
-    w0 = nw0; w1 = nw1;
+    }
   }
   float* out = part + ((size_t)ks * B) * HID + n0 + r;
 #pragma unroll
