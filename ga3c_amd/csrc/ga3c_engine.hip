@@ -190,9 +190,11 @@ struct ga3c_net {
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
   bool d1_heads = false;               // GA3C_D1_HEADS=1: dense1 forward + heads in one launch, last-arriving workgroup of a row tile.
                                        // Measured: 29 us against 5.7 + 5.8 us as two launches (profiles/README.md) -- kept for the record, off
-  int d1f_frag_lanes = 3;              // prediction steps of >= 64 rows use the register-fragment dense1 (no LDS: it shares a CU
+  int d1f_frag_lanes = 2;              // prediction steps of >= 64 rows use the register-fragment dense1 (no LDS: it shares a CU
                                        // with another lane's conv stack, which the 148 KB tile kernel cannot) while at least
                                        // this many prediction calls are in flight (GA3C_D1F_FRAG_LANES; 0 = never).  Same bits.
+                                       // Measured, 1 / 2 / 3 / 4 lanes at 128 rows: threshold 3 -> 5.80 / 7.51 / 9.07 / 10.53 M
+                                       // predictions/s, 2 -> 5.81 / 7.79 / 9.01 / 10.60, 1 -> 5.55 / 7.78 / 8.98 / 10.59
   std::atomic<int> predict_inflight{0};
   bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)

@@ -331,7 +331,7 @@ def test_dense1_heads_single_launch_same_bits(nets, monkeypatch):
 
 
 def test_dense1_fragment_and_tile_kernels_give_the_same_bits(nets, monkeypatch):
-    """The engine picks dense1's register-fragment kernel (no LDS) for prediction steps while three or more lanes are at work,
+    """The engine picks dense1's register-fragment kernel (no LDS) for prediction steps while two or more lanes are at work,
     the LDS-tiled one otherwise: the choice depends on timing, so the two must agree bit for bit (same split-K slices, same
     two-accumulator summation order)."""
     import ga3c_amd  # noqa: F401
