@@ -28,7 +28,11 @@ static int fake_predict_rows(void*, const int64_t* offsets, int32_t batch, int32
 #define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s line %d\n", #c, __LINE__); failures++; } } while (0)
 
 int main(int argc, char** argv) {
-  const int n_agents = 12, n_pred = 3, rounds = argc > 1 ? std::atoi(argv[1]) : 1500, n_act = 6;
+  // queue_stress [rounds] [agents] [plain predictor threads]: the defaults oversubscribe lightly; "300 96 4" is a herd of
+  // producers behind few consumers (the shape that collapsed the CAS-loop ring: every respond() wakes a batch of agents that
+  // submit at once)
+  const int rounds = argc > 1 ? std::atoi(argv[1]) : 1500, n_agents = argc > 2 ? std::atoi(argv[2]) : 12,
+            n_pred = argc > 3 ? std::atoi(argv[3]) : 3, n_act = 6;
   ga3c_shm_config cfg;
   std::memset(&cfg, 0, sizeof cfg);
   cfg.max_agents = n_agents; cfg.num_actions = n_act; cfg.state_bytes = 64; cfg.train_slots = 4; cfg.train_rows = 6;

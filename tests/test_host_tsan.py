@@ -26,3 +26,24 @@ def test_transport_stress_is_sanitizer_clean(tmp_path, sanitizer):
         assert pr.returncode == 0, out + err
         assert "WARNING: ThreadSanitizer" not in err and "ERROR: AddressSanitizer" not in err, err
         assert "failures 0" in out
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("sanitizer", ["thread", None])
+def test_a_herd_of_agents_behind_few_predictors(tmp_path, sanitizer):
+    """96 agent threads, 1 native predictor loop + 4 plain ones: every request answered once with its own values, every
+    rollout trained once.  The ring's push is a ticket (fetch_add) since a compare-and-swap loop collapsed under such herds
+    (profiles/README.md); this holds it to the same invariants as the small case, with and without ThreadSanitizer."""
+    exe = str(tmp_path / "queue_herd")
+    cmd = ["g++", "-std=c++17", "-O2" if sanitizer is None else "-O1", "-g", "-pthread"]
+    if sanitizer:
+        cmd += ["-fsanitize=" + sanitizer, "-fno-omit-frame-pointer"]
+    cmd += [os.path.join(ROOT, "tests", "native", "queue_stress.cpp"), os.path.join(ROOT, "ga3c_amd", "csrc", "ga3c_host.cpp"),
+            "-o", exe, "-lrt"]
+    subprocess.check_call(cmd)
+    pr = subprocess.run([exe, "200" if sanitizer is None else "60", "96", "4"], capture_output=True, text=True, timeout=240)
+    if sanitizer == "thread" and "FATAL: ThreadSanitizer" in pr.stderr and "unexpected memory mapping" in pr.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this container")
+    assert pr.returncode == 0, pr.stdout + pr.stderr
+    assert "WARNING: ThreadSanitizer" not in pr.stderr, pr.stderr
+    assert "failures 0" in pr.stdout
