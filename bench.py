@@ -10,10 +10,11 @@ A step is one pass of the hot path over one batch that is already resident in HB
   predict leg (the headline `value`): one ThreadPredictor batch (BASELINE.json configs[1]:
       batch = 128 states) through the HIP NetworkVP forward -> p, v.  The K steps are dealt round-robin to
       NP prediction lanes = predictor threads, each lane with its own HIP stream and workspace exactly as
-      ThreadPredictor uses them.  NP = 4 (--predictors): the reference starts with Config.PREDICTORS = 2
-      (Config.py:57, README.md:28-32 "NP: 2") and walks NP at run time (ThreadDynamicAdjustment); on the MI355X
-      four lanes on eight hardware queues are the best setting (profiles/README.md).  The 1-, 2- and 3-lane
-      figures of the same K steps are reported beside it under "predict_lanes";
+      ThreadPredictor uses them.  NP = 2 (--predictors): the reference's and this package's default
+      Config.PREDICTORS = 2 (Config.py:57, README.md:28-32 "NP: 2"), on the HIP runtime's default number of
+      hardware queues -- the configuration a Server with Config defaults runs.  The 1-, 3- and 4-lane figures of
+      the same K steps are reported beside it under "predict_lanes", and the 8-hardware-queue variant (a process-wide
+      runtime setting the package does not make) under "predict_lanes_8_hw_queues", measured in a child process;
   train leg (reported under "train"): one ThreadTrainer batch (configs[2]: 128 rows) through forward,
       loss, backward, RCCL all-reduce of the gradient arena when N > 1, RMSProp.
 Per-GPU work is fixed as N grows (weak scaling); predictions need no collective.
@@ -29,9 +30,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this stack
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")            # a hardware queue per lane for the resident legs (4 lanes: 7.5 -> 9.3 M
-                                                           # predictions/s); must be set before HIP initialises.  The engine legs
-                                                           # (2 predictor threads) are indifferent to it (profiles/README.md)
+# GPU_MAX_HW_QUEUES is NOT touched: every leg of this process runs on the runtime's default, like the package itself
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -134,7 +133,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--actions", type=int, default=6)
-    ap.add_argument("--predictors", type=int, default=4, help="prediction lanes the K predict steps are dealt to (predictor threads)")
+    ap.add_argument("--predictors", type=int, default=2, help="prediction lanes the K predict steps are dealt to (predictor threads; "
+                                                               "Config.PREDICTORS = 2 is the reference's and the package's default)")
+    ap.add_argument("--lanes-only", action="store_true",
+                    help="child mode of the 8-hardware-queue extra: print only {lanes: predictions/s} for 1..4 lanes and exit")
     ap.add_argument("--no-lane-sweep", action="store_true",
                     help="skip the extra 1- and 3-lane legs (use with --predictors 1 under rocprofv3 so that kernels never overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length; 0 disables it")
@@ -174,7 +176,10 @@ def main():
     B, A, K, W = args.batch, args.actions, args.steps, args.warmup
     Config.PREDICTION_BATCH_SIZE = B
     NP = max(1, args.predictors)
-    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=B, predict_lanes=max(NP, 4))
+    # ThreadTrainer assembles TRAINING_MIN_BATCH_SIZE + 1 .. + TIME_MAX + 1 rows (ThreadTrainer.py:49-59): with the
+    # "batch = 128" setting (MIN = 127) that is 128 .. 132 + 1; the extra train leg below times the 132-row step
+    TB = B + Config.TIME_MAX - 1
+    net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=TB, predict_lanes=max(NP, 4))
     lib, h = net._lib, net._h
 
     import DataParallel
@@ -191,10 +196,11 @@ def main():
 
     # synthetic inputs of the reference's shape and value set
     rng = np.random.Generator(np.random.PCG64(12345 + rank))
-    x = rng.integers(0, 256, size=(B, 84, 84, 4), dtype=np.uint8).astype(np.float32) / np.float32(128) - np.float32(1)
-    act = np.eye(A, dtype=np.float32)[rng.integers(0, A, B)]
-    y_r = rng.uniform(-1, 1, B).astype(np.float32)
-    nat.check(lib.ga3c_net_upload(h, nat.ptr(x), nat.ptr(y_r), nat.ptr(act), B), "upload")
+    x_tb = rng.integers(0, 256, size=(TB, 84, 84, 4), dtype=np.uint8).astype(np.float32) / np.float32(128) - np.float32(1)
+    act_tb = np.eye(A, dtype=np.float32)[rng.integers(0, A, TB)]
+    y_r_tb = rng.uniform(-1, 1, TB).astype(np.float32)
+    x, act, y_r = x_tb[:B], act_tb[:B], y_r_tb[:B]
+    nat.check(lib.ga3c_net_upload(h, nat.ptr(x_tb), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload")
     lr, beta = float(Config.LEARNING_RATE_START), float(Config.BETA_START)
 
     def barrier_sync():
@@ -202,15 +208,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_block(mode, steps, lanes=0):
+    def timed_block(mode, steps, lanes=0, rows=None):
         """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks of the wall time."""
         ev_ms = nat.C.c_float()
+        rows = B if rows is None else rows
         barrier_sync()
         t0 = time.perf_counter()
         if lanes:
-            nat.check(lib.ga3c_net_time_predict_lanes(h, B, steps, lanes, nat.C.byref(ev_ms)), "time_predict_lanes")
+            nat.check(lib.ga3c_net_time_predict_lanes(h, rows, steps, lanes, nat.C.byref(ev_ms)), "time_predict_lanes")
         else:
-            nat.check(lib.ga3c_net_time_resident(h, mode, B, steps, lr, beta, nat.C.byref(ev_ms)), "time_resident")
+            nat.check(lib.ga3c_net_time_resident(h, mode, rows, steps, lr, beta, nat.C.byref(ev_ms)), "time_resident")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if world > 1:
@@ -223,13 +230,13 @@ def main():
     MIN_TIMED_S, MAX_BLOCKS = 0.05, 400
     blocks_used = {}
 
-    def timed(mode, steps, lanes=0, tag=None):
+    def timed(mode, steps, lanes=0, tag=None, rows=None):
         """A K-step block of this path lasts well under a millisecond at the driver's K = 20, which is mostly the start-up
         of the streams: the bracketed K-step block is repeated until at least 50 ms have been timed and the MEDIAN block
         is reported (every rank runs the same number of blocks: the count is decided on rank 0's clock)."""
         walls, evs, total = [], [], 0.0
         while True:
-            w, e = timed_block(mode, steps, lanes)
+            w, e = timed_block(mode, steps, lanes, rows)
             walls.append(w)
             evs.append(e)
             total += w
@@ -250,7 +257,12 @@ def main():
             nat.check(lib.ga3c_net_time_resident(h, mode, B, W, lr, beta, nat.C.byref(ev_ms)), "warmup")
     if W > 0:
         nat.check(lib.ga3c_net_time_predict_lanes(h, B, W, NP, nat.C.byref(ev_ms)), "warmup")
-    pred_s, _ = timed(0, K, lanes=NP, tag="predict")
+    if args.lanes_only:      # child of the 8-hardware-queue extra (see below): the lane sweep and nothing else
+        res = {str(nl): K * B / timed(0, K, lanes=nl)[0] for nl in (1, 2, 3, 4)}
+        net.close()
+        print(json.dumps(dict(res, hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES"))))
+        return
+    pred_s, pred_inner_ms = timed(0, K, lanes=NP, tag="predict")
     one_s, pred_ev_ms = timed(0, K)
     sweep = {}
     if not args.no_lane_sweep:
@@ -275,26 +287,29 @@ def main():
                     "train": None, "roofline": None, "cpu_baseline": None,
                     "error": "a data-parallel (RCCL) leg did not finish within 300 s; predictions need no collective and are reported"}),
                     flush=True)
-            os._exit(0)
+            os._exit(3)      # a process that gives up on a GPU collective must not look like a clean run (every rank exits non-zero)
         dp_guard = threading.Timer(300.0, give_up_dp)
         dp_guard.daemon = True
         dp_guard.start()
     if dp_error is None:
         train_s, train_ev_ms = timed(1, K, tag="train")
+        train_tb_s, _ = timed(1, K, rows=TB)            # what the engine's trainers really assemble at MIN = B - 1
     else:                                               # no communicator: the data-parallel train leg is not measured
-        train_s, train_ev_ms = None, None
+        train_s, train_ev_ms, train_tb_s = None, None, None
     allreduce_us = None
     if world > 1 and dp_error is None:      # the exchange step alone: 4.02 MB f32 sum all-reduce, events on the train stream
         barrier_sync()
         nat.check(lib.ga3c_net_time_allreduce(h, 50, nat.C.byref(ev_ms)), "time_allreduce")
         allreduce_us = ev_ms.value / 50 * 1e3
     # the engine's own intake format: uint8 frames resident in HBM, converted inside the conv kernels (extra figure)
-    xk = np.ascontiguousarray(((x + np.float32(1)) * np.float32(128)).astype(np.uint8))
-    nat.check(lib.ga3c_net_upload_u8(h, nat.ptr(xk, nat.u8p), nat.ptr(y_r), nat.ptr(act), B), "upload_u8")
+    xk = np.ascontiguousarray(((x_tb + np.float32(1)) * np.float32(128)).astype(np.uint8))
+    nat.check(lib.ga3c_net_upload_u8(h, nat.ptr(xk, nat.u8p), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload_u8")
     nat.check(lib.ga3c_net_time_predict_lanes(h, B, max(W, 1), NP, nat.C.byref(ev_ms)), "warmup")
     u8_s, _ = timed(0, K, lanes=NP)
     u8_train_s = timed(1, K)[0] if dp_error is None else None
-    nat.check(lib.ga3c_net_upload(h, nat.ptr(x), nat.ptr(y_r), nat.ptr(act), B), "upload")
+    u8_train_tb_s = timed(1, K, rows=TB)[0] if dp_error is None else None
+    nat.check(lib.ga3c_net_upload(h, nat.ptr(x_tb), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload")
+    comm_ranks, comm_rank, comm_dev = net.comm_info()
     if dp_guard is not None:
         dp_guard.cancel()
 
@@ -312,26 +327,35 @@ def main():
                        "inputs": "resident in HBM (f32 NHWC), outputs p,v left in HBM"},
             "predict_lanes": dict({"1": world * K * B / one_s, str(NP): pps},
                                   **{str(nl): world * K * B / s_ for nl, s_ in sweep.items()},
-                                  unit="predictions/s", hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
-                                  note="same K steps dealt to 1 .. 4 prediction lanes; `value` is the NP-lane figure "
-                                       "(the reference's default NP = 2 is the \"2\" entry)"),
+                                  unit="predictions/s", hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                                  note="same K steps dealt to 1 .. 4 prediction lanes (one persistent host thread per lane); "
+                                       "`value` is the NP = %d figure, the default of the reference and of this package" % NP),
+            "ms_per_step_inner": pred_inner_ms / K,
             "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
                       "ms_per_step": train_s / K * 1e3 if train_s else None, "rows_per_step": world * B,
                       "trained_samples_per_sec": world * K * B / train_s if train_s else None,
                       "workload": "forward+loss+backward%s+RMSProp, %d rows per GPU (BASELINE configs[2])"
-                                  % ("+RCCL all-reduce(sum) of 4.02 MB grads" if world > 1 else "", B)},
+                                  % ("+RCCL all-reduce(sum) of 4.02 MB grads" if world > 1 else "", B),
+                      "train_%d" % TB: {"rows_per_step": world * TB, "ms_per_step": train_tb_s / K * 1e3 if train_tb_s else None,
+                                         "steps_per_sec": K / train_tb_s if train_tb_s else None,
+                                         "note": "the largest batch ThreadTrainer assembles at TRAINING_MIN_BATCH_SIZE = %d "
+                                                 "(ThreadTrainer.py:49-59): MIN + TIME_MAX rows" % (B - 1)}},
             "stream_ms_per_step": {"predict": pred_ev_ms / K, "train": train_ev_ms / K if train_ev_ms else None},
             "timed_blocks": dict(blocks_used, min_timed_ms=MIN_TIMED_S * 1e3,
                                  note="the bracketed K-step block is repeated until >= 50 ms are timed; ms_per_step and "
                                       "value are those of the MEDIAN block"),
             "data_parallel_error": dp_error,
-            "rccl_ranks": world if (world > 1 and dp_error is None) else (1 if world == 1 else 0),
+            "rccl_ranks": comm_ranks if world > 1 else 1,
+            "rccl_comm": {"ranks": comm_ranks, "rank": comm_rank, "device": comm_dev,
+                          "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the attached communicator "
+                                    "(ga3c_net_comm_info); 0 / -1 / -1 = no communicator (N = 1 attaches none)"},
             "allreduce_us": allreduce_us,
             "allreduce_note": "average of 50 back-to-back ncclAllReduce(sum, f32, 1,005,623 elements = 4.02 MB) on the train "
                               "stream, HIP events around them; inside a train step the dense1/w part overlaps with the conv "
                               "backward kernels" if world > 1 else None,
             "uint8_resident": {"predictions_per_sec": world * K * B / u8_s,
                                "training_steps_per_sec": K / u8_train_s if u8_train_s else None,
+                               "training_steps_per_sec_%d_rows" % TB: K / u8_train_tb_s if u8_train_tb_s else None,
                                "note": "same legs with the batch resident as uint8 frames (28,224 B per state), the "
                                        "format the shared-memory transport delivers; bit-identical results"},
         }
@@ -357,7 +381,7 @@ def main():
             traffic = tj.get("conv_stack_fwd_B%d" % B)
             traffic_commit, traffic_src = tj.get("commit"), tj.get("source")
             prof_us = tj.get("conv_stack_fwd_B%d_rocprof_avg_us" % B)
-        out["roofline"] = {"kernel": "conv_stack_fwd_kernel<false>", "bound": "mfma", "achieved": achieved,
+        out["roofline"] = {"kernel": "conv_stack_fwd_kernel<false, false>", "bound": "mfma", "achieved": achieved,
                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                            "traffic": traffic, "traffic_commit": traffic_commit, "traffic_source": traffic_src,
                            "avg_launch_us": kernels["conv_stack_fwd"], "algorithmic_flop_per_launch": flop_launch,
@@ -415,6 +439,22 @@ def main():
 
     cpu_theta = net.get_arena(0) if (rank == 0 and world == 1 and args.cpu_seconds > 0) else None
     net.close()
+
+    # ---- extra: the same lane sweep with 8 hardware queues.  GPU_MAX_HW_QUEUES is read once, when HIP initialises, and is
+    # process-wide, so this runs in a child process; the package itself leaves the runtime's default (ga3c_amd/__init__.py)
+    if rank == 0 and world == 1 and not args.no_lane_sweep:
+        import subprocess
+        try:
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--lanes-only", "--steps", str(max(K, 100)),
+                                    "--warmup", str(max(W, 10)), "--batch", str(B), "--actions", str(A)],
+                                   env=dict(os.environ, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True, timeout=240)
+            line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+            out["predict_lanes_8_hw_queues"] = dict(json.loads(line[-1]), unit="predictions/s",
+                                                    note="child process with GPU_MAX_HW_QUEUES=8 (a queue per lane): an "
+                                                         "extra, not the product's configuration") if line else \
+                {"error": "child printed no line (rc %d): %s" % (child.returncode, child.stderr[-300:])}
+        except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+            out["predict_lanes_8_hw_queues"] = {"error": repr(e)}
 
     # ---- Hogwild trainers: the reference's default NT = 2 trainer threads update shared weights unlocked (Server.py:132-134)
     if rank == 0 and world == 1:
@@ -493,7 +533,7 @@ def main():
         half = max(4.0, args.e2e_seconds * 0.75)
         keys = ("predictions_per_sec", "training_steps_per_sec", "mean_predict_batch", "seconds", "agents", "predictors")
         raw = {}
-        for mult, npred in ((1, 2), (2, 4)):
+        for mult, npred in ((1, 2), (2, 2)):      # Config.PREDICTORS = 2 for both (4 predictor threads + 2 trainers: see profiles/README.md)
             raw["agents_x%d" % mult] = {
                 mode: {k: r[k] for k in keys}
                 for mode, r in ((m, run_engine(None, half, mult * args.e2e_agents, B, A, frames="rgb-" + m, predictors=npred))
@@ -530,7 +570,7 @@ def main():
             if rank == 0:
                 out["e2e"] = {"error": "the %d-rank engine leg did not finish within its time limit" % world}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)      # the line is kept, the status says that a collective leg hung
         guard = threading.Timer(args.e2e_seconds + 90.0, give_up)
         guard.daemon = True
         guard.start()

@@ -28,6 +28,18 @@ import numpy as np
 RENDEZVOUS_TIMEOUT_S = 300.0
 
 
+def _private_dir():
+    """Where the rendezvous files live unless GA3C_DP_DIR says otherwise: a directory of this user's own (0700) under the
+    temp dir.  All ranks must see the same directory -- one node, or GA3C_DP_DIR on storage the nodes share."""
+    d = os.path.join(tempfile.gettempdir(), "ga3c_dp_%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("%s is not a private directory of this user; set GA3C_DP_DIR" % d)
+    return d
+
+
 def shard_bounds(rows, rank, world):
     """Contiguous [lo, hi) of `rows` owned by `rank`; the first rows % world ranks get one extra row."""
     base, extra = divmod(int(rows), int(world))
@@ -57,7 +69,7 @@ class Rendezvous:
         self.rank, self.world = int(rank), int(world)
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = port or os.environ.get("MASTER_PORT", "29500")
-        directory = directory or os.environ.get("GA3C_DP_DIR", tempfile.gettempdir())
+        directory = directory or os.environ.get("GA3C_DP_DIR") or _private_dir()
         self.path = os.path.join(directory, "ga3c_rendezvous_%s_%s_%s.json" % (str(addr).replace(":", "_"), port, tag))
         self.peers = []          # rank 0: sockets of ranks 1..world-1, in rank order
         self.up = None           # other ranks: the socket to rank 0
@@ -77,10 +89,13 @@ class Rendezvous:
         except OSError:
             srv.bind(("127.0.0.1", 0))
         srv.listen(self.world)
-        tmp = "%s.%d.tmp" % (self.path, os.getpid())
-        with open(tmp, "w") as f:
+        # the file carries the token that admits a rank: readable by its owner only, never written through a link somebody
+        # else planted (O_EXCL | O_NOFOLLOW on a fresh name, then an atomic rename over a stale file of an earlier run)
+        tmp = "%s.%d.%s.tmp" % (self.path, os.getpid(), os.urandom(4).hex())
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+        with os.fdopen(fd, "w") as f:
             json.dump({"host": srv.getsockname()[0], "port": srv.getsockname()[1], "token": token, "world": self.world}, f)
-        os.replace(tmp, self.path)         # a stale file of an earlier run on the same MASTER_PORT is replaced atomically
+        os.replace(tmp, self.path)
         atexit.register(self._unlink)
         got = {}
         srv.settimeout(RENDEZVOUS_TIMEOUT_S)
@@ -186,7 +201,12 @@ def attach(net, rank, world, rendezvous=None):
     return net
 
 
-_MSG = struct.Struct("<qqddi4x")          # credit, from_step, lr, beta, stop
+_MSG = struct.Struct("<qqddi4x")          # credit, from_step, lr, beta, stop (2: abort, from_step = the late rank)
+_UP = struct.Struct("<qq")                # rank r -> rank 0: steps finished, steps started
+
+
+class GroupStalled(RuntimeError):
+    """A rank has kept the others waiting inside a collective (or for credit) for longer than EngineGroup.STALL_S."""
 
 
 class EngineGroup:
@@ -201,6 +221,7 @@ class EngineGroup:
     the replicas apply identical updates.
     """
     WINDOW = 64          # least number of steps of credit ahead of rank 0's own step count
+    STALL_S = 120.0      # a rank that keeps the others inside a collective this long is named and the group stops
 
     def __init__(self, rank, world, rendezvous=None):
         self.rank, self.world = rank, world
@@ -209,6 +230,15 @@ class EngineGroup:
         self.stopping = False            # the credit is final
         self.schedule = []               # (from_step, lr, beta): steps > from_step use lr, beta (until the next entry)
         self._last_step, self._pace = 0, 0
+        # progress as each rank reports it: a train step that contains an all-reduce completes on every rank or on none,
+        # so "finished" counts never differ -- the rank that is late is the one that has not STARTED the step the others
+        # are waiting in.  Server bumps `started` (under dp_lock) right before it calls the model.
+        self.STALL_S = float(os.environ.get("GA3C_DP_STALL_S", self.STALL_S))
+        self.started = 0
+        self.failure = None              # GroupStalled once the group has been given up (every rank gets the same text)
+        now = time.time()
+        self._peer = [[0, 0, None] for _ in range(world)]    # rank 0: [finished, started, since when behind the others]
+        self._heard = now                                    # other ranks: when rank 0 last spoke
 
     @classmethod
     def from_env(cls):
@@ -243,10 +273,59 @@ class EngineGroup:
         self.credit = max(self.credit, credit)
         self.stopping = self.stopping or bool(stop)
 
+    def note_started(self, step):
+        """Server: this rank is about to enter train step `step` (1-based)."""
+        self.started = max(self.started, step)
+
+    def _late_rank(self, now):
+        """Rank 0: the rank that has not started the step the others have been waiting in for STALL_S, or None."""
+        ahead = max(p[1] for p in self._peer)
+        late = []
+        for r, p in enumerate(self._peer):
+            if p[1] >= ahead:
+                p[2] = None
+            elif p[2] is None:
+                p[2] = now                       # from now on somebody waits for this rank
+            elif now - p[2] > self.STALL_S:
+                late.append((p[1], r))
+        return min(late)[1] if late else None
+
+    def _give_up(self, late, now):
+        p = self._peer[late]
+        self.failure = GroupStalled("rank %d has not started train step %d for %.0f s while the other ranks wait for it in "
+                                    "that step's all-reduce (it has finished %d steps)"
+                                    % (late, max(q[1] for q in self._peer), now - p[2], p[0]))
+        self.stopping = True
+        msg = _MSG.pack(self.credit, late, 0.0, 0.0, 2)
+        for s in self.rv.peers:
+            try:
+                s.sendall(msg)
+            except OSError:
+                pass
+        raise self.failure
+
     def poll(self, want_stop, current_step, lr, beta):
         """Call once per main-loop turn (Server.main).  Rank 0 extends the credit and announces it; the other ranks take
-        in whatever has arrived.  Never blocks."""
+        in whatever has arrived and report their progress.  Never blocks.  Raises GroupStalled (on every rank, naming the
+        same late rank) when a rank has kept the group waiting for STALL_S."""
+        if self.failure is not None:
+            raise self.failure
+        now = time.time()
         if self.rank == 0:
+            self._peer[0][0], self._peer[0][1] = current_step, self.started
+            for r, s in enumerate(self.rv.peers, start=1):
+                while True:
+                    ready, _, _ = select.select([s], [], [], 0)
+                    if not ready:
+                        break
+                    try:
+                        fin, sta = _UP.unpack(_recv_exact(s, _UP.size))
+                    except (ConnectionError, OSError):
+                        break                    # that rank has left (after the stop, or it died: the stall rule names it)
+                    self._peer[r][0], self._peer[r][1] = fin, sta
+            late = self._late_rank(now)
+            if late is not None:
+                self._give_up(late, now)
             if not self.stopping:
                 self._pace = max(self._pace // 2, current_step - self._last_step)      # steps per poll, recent peak
                 self._last_step = current_step
@@ -258,6 +337,11 @@ class EngineGroup:
                 for s in self.rv.peers:
                     s.sendall(msg)
         else:
+            if self.rv.up is not None:
+                try:
+                    self.rv.up.sendall(_UP.pack(current_step, self.started))
+                except OSError:
+                    pass                         # rank 0 has left: the receive below says whether that was in order
             while self.rv.up is not None:
                 ready, _, _ = select.select([self.rv.up], [], [], 0)
                 if not ready:
@@ -269,7 +353,18 @@ class EngineGroup:
                         raise                    # rank 0 is gone without having said stop
                     self.rv.close()              # rank 0 has left after its last message: nothing more will come
                     break
-                self._apply(*_MSG.unpack(raw))
+                self._heard = now
+                credit, from_step, mlr, mbeta, stop = _MSG.unpack(raw)
+                if stop == 2:
+                    self.stopping = True
+                    self.failure = GroupStalled("rank 0 stopped the group: rank %d did not start a train step the other "
+                                                "ranks were waiting in for %.0f s" % (from_step, self.STALL_S))
+                    raise self.failure
+                self._apply(credit, from_step, mlr, mbeta, stop)
+            if self.rv.up is not None and not self.stopping and now - self._heard > self.STALL_S:
+                self.failure = GroupStalled("rank %d has heard nothing from rank 0 for %.0f s (no step credit)"
+                                            % (self.rank, now - self._heard))
+                raise self.failure
         return self.credit
 
     def close(self):

@@ -36,6 +36,15 @@ if __name__ == '__main__':
     try:
         # raises (non-zero exit status) if a predictor / trainer thread died
         Server(engine_group=group).main(max_seconds=Config.MAX_SECONDS or None)
+    except RuntimeError as e:
+        if isinstance(e.__cause__, DataParallel.GroupStalled):
+            # a rank kept the others inside an all-reduce: trainer threads and the train stream are stuck in it, so no
+            # orderly teardown of the GPU side is possible -- say who was late and end the process with a failure status
+            import os
+            sys.stderr.write("GA3C: %s\n" % e.__cause__)
+            sys.stderr.flush()
+            os._exit(3)
+        raise
     finally:
         if group is not None:
             group.close()

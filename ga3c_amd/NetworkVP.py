@@ -392,6 +392,12 @@ class Network:
         comm_id = np.ascontiguousarray(comm_id, dtype=np.uint8)
         nat.check(self._lib.ga3c_net_comm_init(self._h, nat.ptr(comm_id, nat.u8p), rank, world), "ga3c_net_comm_init")
 
+    def comm_info(self):
+        """(ranks, rank, device) as the attached RCCL communicator reports them; (0, -1, -1) without one."""
+        n, r, d = nat.C.c_int32(), nat.C.c_int32(), nat.C.c_int32()
+        nat.check(self._lib.ga3c_net_comm_info(self._h, nat.C.byref(n), nat.C.byref(r), nat.C.byref(d)), "ga3c_net_comm_info")
+        return n.value, r.value, d.value
+
     # ---- logging / checkpoints -----------------------------------------------------------------
     def evaluate(self, x, y_r, a, offsets=None, frames=None):
         """Forward + loss of the batch on the current weights, no update: what sess.run(summary_op) evaluates

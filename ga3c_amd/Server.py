@@ -137,7 +137,8 @@ class Server:
 
     def remove_trainer(self):
         self.trainers[-1].exit_flag = True
-        self.trainers[-1].join()
+        # after a failure a trainer may sit inside a collective its peers never join: it is a daemon thread, leave it
+        self.trainers[-1].join(None if self.failure is None else 5.0)
         self.trainers.pop()
 
     # ---- training bookkeeping (Server.py:141-153) ----------------------------------------------
@@ -146,11 +147,19 @@ class Server:
         learning rate and beta that rank 0 attached to that step.  False = the group is stopping and this rank has
         taken its last step (the batch is dropped, as the reference drops what is queued at exit)."""
         dp = self.dp
+        t0 = time.time()
         while not dp.may_step(self.training_step):
             if dp.finished(self.training_step) or self.closing or self.failure is not None:
                 return False
+            if time.time() - t0 > dp.STALL_S:
+                # bounded: the main loop's poll() normally reports this first (and names the rank); a trainer thread that
+                # has waited this long for credit reports it itself rather than stall for ever
+                self.worker_failed("data-parallel group", DataParallel.GroupStalled(
+                    "rank %d: no credit for train step %d from rank 0 for %.0f s" % (dp.rank, self.training_step + 1, time.time() - t0)))
+                return False
             time.sleep(0.0005)
         self.model.learning_rate, self.model.beta = dp.rates_for(self.training_step + 1)
+        dp.note_started(self.training_step + 1)
         return True
 
     def train_model(self, x_, r_, a_, x2, done, trainer_id):
@@ -224,7 +233,11 @@ class Server:
                 if self.dp is not None:
                     # rank 0 decides when to stop and which lr / beta each step uses; every rank leaves on the same step
                     want_stop = timed_out or self.stats.episode_count.value >= Config.EPISODES
-                    self.dp.poll(want_stop, self.training_step, lr, beta)
+                    try:
+                        self.dp.poll(want_stop, self.training_step, lr, beta)
+                    except DataParallel.GroupStalled as e:       # a rank keeps the others inside a collective: give up, say who
+                        self.worker_failed("data-parallel group", e)
+                        break
                     if self.dp.finished(self.training_step):
                         break
                 else:
@@ -253,10 +266,12 @@ class Server:
             self.remove_trainer()
         if self.stats.is_alive():
             self.stats.terminate()
-        if self.zero_copy:
-            self.model.unregister_transport()       # unpin before the segment is unmapped
-            self.zero_copy = False
-        self.transport.close()
+        stalled = self.failure is not None and isinstance(self.failure[1], DataParallel.GroupStalled)
+        if self.zero_copy and not stalled:          # (a stalled group: the train stream sits in a collective that never
+            self.model.unregister_transport()       # completes and a device sync would hang -- the caller ends the process)
+            self.zero_copy = False                  # unpin before the segment is unmapped
+        if not stalled:
+            self.transport.close()
 
     @staticmethod
     def get_state_dim():

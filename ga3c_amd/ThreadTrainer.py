@@ -68,6 +68,7 @@ class ThreadTrainer(Thread):
             batch_size = 0
             held = []                                   # zero-copy: (slot, first row, rows) stay ours until the GPU has read them
             spilled = False
+            starved = False
             cstate[:] = 0
             if turn:
                 while not turn.acquire(timeout=Config.QUEUE_TIMEOUT_MS / 1000.0):
@@ -81,7 +82,12 @@ class ThreadTrainer(Thread):
                         batch_size = int(cstate[0])
                         if rc == -4:
                             return                      # transport shut down
-                        if rc == 1:                     # starved: rebuild the held list and fall into the spill below
+                        if rc == 1:
+                            # starved: rebuild the held list and spill.  The native call has already seen "nothing free,
+                            # nothing queued" while these slots were held; the counts are NOT looked at again here -- an
+                            # agent that commits in between would skip the spill and leave the rows of `held` to be
+                            # overwritten by the next collect (round-2 advice)
+                            starved = True
                             first = 0
                             for slot in slot_stage[:cstate[1]]:
                                 rows = t.rows(int(slot))
@@ -90,7 +96,8 @@ class ThreadTrainer(Thread):
                             cstate[1] = 0
                         else:
                             continue                    # complete (the loop condition ends it) or timeout
-                    if held and t.free_count() == 0 and t.ready_count() == 0:
+                    if held and (starved or (t.free_count() == 0 and t.ready_count() == 0)):
+                        starved = False
                         # every slot is ours or another trainer's and the agents are waiting for one: spill
                         if x_stage is None:
                             x_stage = alloc(shape, np.uint8) if alloc else np.zeros(shape, np.uint8)

@@ -7,6 +7,7 @@
 #include <fcntl.h>
 #include <linux/futex.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
@@ -105,8 +106,26 @@ void ring_init(char* base, Ring* r, uint32_t cap_pow2, int64_t cells_off) {
 // entry per rollout slot, capacity many times that), so a ticket's cell is free unless the consumer of the previous lap
 // has claimed it (CAS on deq) and was descheduled before republishing its sequence number: that is a wait for a peer
 // thread -- yield a few times, then nap with a doubling back-off; `closed` ends it.
+//
+// A ticket that has been taken must be filled: a producer that dies between the fetch_add and the sequence store leaves
+// a hole no consumer can pass.  Server.remove_agent ends an agent that does not leave by itself with SIGTERM
+// (Process.terminate), so asynchronous signals are held back for the few instructions between ticket and publication
+// (two rt_sigprocmask calls, ~0.2 us, against an agent step of ~28 us); SIGKILL cannot be held back and may still wedge
+// a ring -- the transport has to be recreated then.  On `closed` the cell is abandoned on purpose: every consumer treats
+// a closed segment as drained.
+struct SignalHold {
+  sigset_t old;
+  SignalHold() {
+    sigset_t all;
+    sigfillset(&all);
+    pthread_sigmask(SIG_BLOCK, &all, &old);
+  }
+  ~SignalHold() { pthread_sigmask(SIG_SETMASK, &old, nullptr); }
+};
+
 bool ring_push(char* base, Ring* r, uint32_t v, const std::atomic<uint32_t>* closed) {
   Cell* c = cells(base, r);
+  SignalHold hold;
   const uint64_t pos = r->enq.fetch_add(1, std::memory_order_relaxed);
   Cell* cell = &c[pos & r->mask];
   int64_t nap_ns = 50000;

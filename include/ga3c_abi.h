@@ -202,6 +202,9 @@ int ga3c_host_free(void* ptr);
 #define GA3C_COMM_ID_BYTES 128
 int ga3c_comm_make_id(uint8_t id[GA3C_COMM_ID_BYTES]);
 int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int32_t rank, int32_t world);
+/* What the attached communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), not what the
+ * launcher's environment claims: ranks = 0 and rank = -1 while no communicator is attached.  bench.py's `rccl_ranks`. */
+int ga3c_net_comm_info(ga3c_net* net, int32_t* ranks, int32_t* rank, int32_t* device);
 /* `iters` back-to-back all-reduces of the gradient arena between two HIP events on the train stream (bench.py's
  * allreduce_us).  Collective: every rank of the communicator calls it. */
 int ga3c_net_time_allreduce(ga3c_net* net, int32_t iters, float* elapsed_ms);

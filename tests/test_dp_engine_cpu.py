@@ -154,3 +154,72 @@ def test_credit_protocol_under_fast_steps_and_a_late_rank(tmp_path):
     assert not errors, errors
     assert all(done) and steps[0] == steps[1] > 1000, steps
     assert used[0] == used[1] and 99.0 not in used[0] and len(set(used[0])) > 1
+
+
+def test_a_rank_that_never_joins_a_step_is_named_and_the_group_stops(tmp_path, monkeypatch):
+    """Round-2 verdict, item 7: lock-step training stalls every rank inside the next all-reduce when one rank is starved.
+    The wait is bounded: rank 0 sees that rank 1 has not STARTED the step the others wait in, names it, and every rank's
+    poll() raises GroupStalled with that name (Server.main turns it into worker_failed -> non-zero exit)."""
+    import threading
+    import time
+    import ga3c_amd  # noqa: F401
+    import DataParallel as dp
+    monkeypatch.setenv("GA3C_DP_STALL_S", "0.5")
+    world, port = 3, 46000 + os.getpid() % 10000
+    groups = [None] * world
+
+    def make(rank):
+        groups[rank] = dp.EngineGroup(rank, world, dp.Rendezvous(rank, world, tag="s", addr="127.0.0.1", port=port,
+                                                                  directory=str(tmp_path)))
+    ths = [threading.Thread(target=make, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30)
+    assert all(groups) and groups[0].STALL_S == 0.5
+    steps, raised = [0] * world, [None] * world
+    collective = threading.Barrier(world)
+    halt = threading.Event()
+
+    def trainer(rank):
+        g = groups[rank]
+        while not halt.is_set():
+            if not g.may_step(steps[rank]):
+                time.sleep(0.001)
+                continue
+            if rank == 1 and steps[rank] == 20:
+                halt.wait()                             # starved of rollouts: never starts step 21
+                return
+            g.note_started(steps[rank] + 1)
+            try:
+                collective.wait()
+            except threading.BrokenBarrierError:
+                return
+            steps[rank] += 1
+
+    def main_loop(rank):
+        g = groups[rank]
+        t0 = time.time()
+        while time.time() - t0 < 20:
+            try:
+                g.poll(False, steps[rank], 1e-3, 0.01)
+            except dp.GroupStalled as e:
+                raised[rank] = str(e)
+                return
+            time.sleep(0.01)
+
+    workers = [threading.Thread(target=f, args=(r,), daemon=True) for r in range(world) for f in (trainer, main_loop)]
+    t_start = time.time()
+    for t in workers:
+        t.start()
+    for t in workers[1::2]:
+        t.join(30)
+    took = time.time() - t_start
+    halt.set()
+    collective.abort()
+    for g in groups:
+        g.close()
+    assert all(raised), raised
+    assert "rank 1 " in raised[0] and "train step 21" in raised[0]
+    assert "rank 1 " in raised[1] and "rank 1 " in raised[2]          # every rank names the same late rank
+    assert steps == [20, 20, 20] and took < 10

@@ -109,7 +109,8 @@ class _Server:
 
     def train_model(self, x, r, a, x2, done, tid):
         self.calls.append(dict(rows=int(x.shape[0]), r_sum=float(np.sum(r)), first=float(x.reshape(x.shape[0], -1)[0, 0]),
-                               last=float(x.reshape(x.shape[0], -1)[-1, 0]), a_shape=a.shape, a_dtype=str(a.dtype)))
+                               last=float(x.reshape(x.shape[0], -1)[-1, 0]), a_shape=a.shape, a_dtype=str(a.dtype),
+                               firsts=[int(v) for v in x.reshape(x.shape[0], -1)[:, 0]]))
 
 
 @pytest.mark.parametrize("key", ["predictor_128", "predictor_32"])
@@ -292,6 +293,60 @@ def test_zero_copy_trainer_spills_when_the_agents_run_out_of_slots(mods, native)
         assert th.spills == 1
         assert len(srv.calls) == 1 and srv.calls[0]["rows"] == 25 and srv.calls[0]["r_sum"] == 25.0      # host path: train_model
         assert srv.calls[0]["first"] == 0.0 and srv.calls[0]["last"] == 24.0
+    finally:
+        Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = 0, True
+        t.shutdown()
+        t.close()
+
+
+def test_rollout_committed_between_estarved_and_the_spill_is_not_lost(mods):
+    """Round-2 advice: ga3c_tq_collect reports ESTARVED while an agent is in the middle of filling the last slot; the agent
+    commits before the trainer gets to act on it.  The trainer must still spill the rows it holds (no second look at the
+    counts): every row arrives exactly once, in order, through the host path."""
+    nat, tp, Config = mods
+    from ThreadTrainer import ThreadTrainer
+    t = tp.Transport.create(tp.unique_name("t_race"), 2, 4, 16, 4, 6)
+    try:
+        Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = 24, True       # 5 rollouts of 5 rows = 25 > 24
+
+        def fill(slot, k):
+            states, returns, actions = t.rollout_views(slot)
+            for i in range(5):
+                states[i] = 5 * k + i
+                returns[i] = 1.0
+                actions[i] = 0
+            t.commit(slot, 5)
+
+        for k in range(3):
+            fill(t.acquire(200), k)
+        mid_fill = t.acquire(200)                      # the agent holds the fourth slot: free == 0, ready == 3
+        real_collect, fired = t.collect, []
+
+        def collect(*a, **kw):
+            rc = real_collect(*a, **kw)
+            if rc == 1 and not fired:                  # ... and commits right after the native call has given up
+                fired.append(1)
+                fill(mid_fill, 3)
+            return rc
+        t.collect = collect
+        srv = _RowsServer(t, 4, (16,))
+        th = ThreadTrainer(srv, 0, t)
+        th.start()
+        deadline = time.time() + 10
+        while not fired and time.time() < deadline:
+            time.sleep(0.005)
+        slot = -3
+        while slot == -3 and time.time() < deadline:   # the spill has given slots back: the fifth rollout can be written
+            slot = t.acquire(200)
+        fill(slot, 4)
+        while not srv.calls and time.time() < deadline:
+            time.sleep(0.01)
+        th.exit_flag = True
+        th.join(5)
+        assert fired and th.spills == 1
+        assert len(srv.calls) == 1 and srv.calls[0]["rows"] == 25 and srv.calls[0]["r_sum"] == 25.0
+        assert srv.calls[0]["first"] == 0.0 and srv.calls[0]["last"] == 24.0
+        assert srv.calls[0]["firsts"] == list(range(25))
     finally:
         Config.TRAINING_MIN_BATCH_SIZE, Config.NATIVE_TRAINER = 0, True
         t.shutdown()
@@ -540,6 +595,54 @@ def test_pop_batch_linger_collects_stragglers_only_when_asked(mods):
         t0 = time.time()
         assert t.pop_batch(ids, 1000) == 1                                   # nobody else comes: gives up after linger_us
         assert 0.25 < time.time() - t0 < 0.6
+    finally:
+        t.shutdown()
+        t.close()
+
+
+def test_sigterm_of_a_producer_does_not_wedge_the_rings(mods):
+    """Server.remove_agent ends a stubborn agent with SIGTERM.  A push is "take a ticket, fill its cell": a producer that
+    dies in between would leave a hole no consumer can pass, so ring_push holds signals back for those few instructions.
+    Producers that do nothing but push are killed at random moments; afterwards every committed rollout can still be
+    popped and new pushes still arrive."""
+    import signal
+    import subprocess
+    import sys
+    nat, tp, Config = mods
+    name = tp.unique_name("t_kill")
+    t = tp.Transport.create(name, 2, 4, 16, 256, 2)
+    code = ("import sys; sys.path[:0] = %r\n"
+            "import ga3c_amd, Transport as tp\n"
+            "t = tp.Transport.attach(%r)\n"
+            "print('up', flush=True)\n"
+            "while True:\n"
+            "    s = t.acquire(50)\n"
+            "    if s >= 0: t.commit(s, 1)\n") % ([ROOT, os.path.join(ROOT, "ga3c_amd")], name)
+    try:
+        rng = np.random.default_rng(7)
+        for _ in range(12):
+            pr = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE)
+            assert pr.stdout.readline().strip() == b"up"
+            stop = time.time() + float(rng.uniform(0.002, 0.03))
+            while time.time() < stop:                      # keep the rings turning while the producer runs
+                s = t.pop_rollout(1)
+                if s >= 0:
+                    t.release(s)
+            pr.send_signal(signal.SIGTERM)
+            pr.wait(10)
+            pr.stdout.close()
+        # drain: everything that was committed comes out, without a timeout while the ring says it holds something
+        while t.ready_count() > 0:
+            s = t.pop_rollout(2000)
+            assert s >= 0, "a committed rollout is stuck behind an abandoned ticket"
+            t.release(s)
+        # a killed producer may take the slot it had acquired with it (at most one each); the rings themselves still work
+        assert t.free_count() >= 256 - 12
+        s = t.acquire(1000)
+        assert s >= 0
+        t.commit(s, 1)
+        assert t.pop_rollout(1000) == s
+        t.release(s)
     finally:
         t.shutdown()
         t.close()
