@@ -392,6 +392,16 @@ class Network:
         comm_id = np.ascontiguousarray(comm_id, dtype=np.uint8)
         nat.check(self._lib.ga3c_net_comm_init(self._h, nat.ptr(comm_id, nat.u8p), rank, world), "ga3c_net_comm_init")
 
+    STAT_NAMES = ("predict_calls", "predict_rows", "predict_lane_wait_ns", "predict_launch_ns", "predict_sync_ns",
+                  "predict_weight_waits", "train_calls", "train_rows", "train_stage_ns", "train_lane_wait_ns",
+                  "train_launch_ns", "train_sync_ns", "train_reader_waits")
+
+    def stats(self, reset=False):
+        """Where the engine's calls spend their time (include/ga3c_abi.h: GA3C_STAT_*), as a dict of running totals."""
+        out = np.zeros(len(self.STAT_NAMES), np.int64)
+        nat.check(self._lib.ga3c_net_stats(self._h, nat.ptr(out, nat.i64p), out.size, 1 if reset else 0), "ga3c_net_stats")
+        return dict(zip(self.STAT_NAMES, (int(v) for v in out)))
+
     def comm_info(self):
         """(ranks, rank, device) as the attached RCCL communicator reports them; (0, -1, -1) without one."""
         n, r, d = nat.C.c_int32(), nat.C.c_int32(), nat.C.c_int32()

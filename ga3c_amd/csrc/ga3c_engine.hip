@@ -66,6 +66,10 @@ int fail(int code, const char* fmt, ...) {
     if (_r != GA3C_OK) return _r; \
   } while (0)
 
+inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Fwd {   // forward workspace of one lane (device pointers)
   float *x = nullptr, *n1 = nullptr, *n2 = nullptr, *part = nullptr, *d1 = nullptr, *z = nullptr, *p = nullptr,
         *v = nullptr;
@@ -93,10 +97,36 @@ struct Lane {
 
 enum StepMode { STEP_RESIDENT = 0, STEP_GATHER_U8 = 1, STEP_GATHER_F32 = 2, STEP_QUEUES = 3 };
 
+// Input side of a train step: the batch (states as f32 or uint8, returns, one-hot actions) and the pinned arrays it is
+// staged through.  A train lane has TWO of them and a stream of its own for staging (`gst`): while one trainer thread's step
+// runs on the train stream, the next thread gathers ITS batch out of the transport (3.7 MB over PCIe, ~100 us) into the other
+// intake -- Server.py:132-134 runs NT trainer threads against one model for exactly this overlap.  Steps themselves stay
+// strictly ordered by the lane's mutex (synchronous, reproducible).  Lock order: intake, then lane.
+struct Intake {
+  std::mutex mu;
+  float* x = nullptr;
+  uint8_t* xu8 = nullptr;
+  float *yr = nullptr, *act = nullptr;
+  float* h_in = nullptr;    // pinned: x | y_r | a
+  int64_t* h_off = nullptr; // pinned: per-row byte offsets / plane sequence numbers, read in place by the gather kernels
+  hipEvent_t ready = nullptr;   // recorded on the staging stream behind the batch
+  bool x_u8 = false;
+};
+
+// where a batch is being staged: an intake's buffers (or the lane's currently bound ones) and the stream to stage on
+struct Stage {
+  float* x; uint8_t* xu8; float* yr; float* act; float* h_in; int64_t* h_off;
+  hipStream_t st;
+  bool x_u8;
+};
+
 struct TrainLane {
   std::mutex mu;
   hipStream_t st = nullptr;
-  Fwd f;
+  hipStream_t gst = nullptr;   // staging stream of the intakes
+  Intake in[2];
+  std::atomic<unsigned> in_rr{0};
+  Fwd f;                    // f.x / f.xu8 / f.x_u8, yr, act, h_in, h_off below: the buffers of the intake bound last (bind_intake)
   float *yr = nullptr, *act = nullptr, *dz = nullptr, *dv = nullptr, *lossrow = nullptr, *dd1 = nullptr,
         *dn2 = nullptr, *dn1 = nullptr, *slab2 = nullptr, *slab1 = nullptr, *losses = nullptr, *scales = nullptr;
   float* h_in = nullptr;    // pinned: x | y_r | a
@@ -227,9 +257,13 @@ struct ga3c_net {
   Frames fr;
   TensorTable tt;
   LaneDrivers drv;
+  // where the engine's calls spend their time (ga3c_net_stats): nanoseconds / counts, relaxed atomics
+  std::atomic<int64_t> stat[GA3C_STAT_COUNT];
 };
 
 namespace {
+
+inline void stat_add(ga3c_net* net, int which, int64_t v) { net->stat[which].fetch_add(v, std::memory_order_relaxed); }
 
 int dmalloc(float** p, size_t floats) {
   HIPCHK(hipMalloc((void**)p, floats * sizeof(float)));
@@ -555,7 +589,10 @@ int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* o
       if (hipEventQuery(net->theta_ready[idx]) == hipSuccess) wait = net->must_wait[idx] = false;
     }
   }
-  if (wait) HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
+  if (wait) {
+    HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
+    stat_add(net, GA3C_STAT_PREDICT_WEIGHT_WAITS, 1);
+  }
   CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
@@ -581,6 +618,7 @@ int claim_other_buffer(ga3c_net* net, TrainLane& t, int* idx_out, int* other_out
     if (L->dirty[other]) {
       HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
       L->dirty[other] = false;
+      stat_add(net, GA3C_STAT_TRAIN_READER_WAITS, 1);
     }
   }
   *idx_out = idx;
@@ -656,29 +694,47 @@ int train_apply(ga3c_net* net, TrainLane& t, float lr) {
   return publish_other_buffer(net, t, other);
 }
 
-int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, const float* y_r, const float* a, int B) {
+// the lane's currently bound input buffers, staged on the train stream itself (resident / evaluation paths)
+Stage lane_stage(TrainLane& t) { return Stage{t.f.x, t.f.xu8, t.yr, t.act, t.h_in, t.h_off, t.st, t.f.x_u8}; }
+Stage intake_stage(TrainLane& t, Intake& in) { return Stage{in.x, in.xu8, in.yr, in.act, in.h_in, in.h_off, t.gst, in.x_u8}; }
+
+// make `in` the batch the lane's next step reads (the lane's mutex is held; `in` is held by the same thread)
+void bind_intake(TrainLane& t, Intake& in) {
+  t.f.x = in.x; t.f.xu8 = in.xu8; t.f.x_u8 = in.x_u8;
+  t.yr = in.yr; t.act = in.act; t.h_in = in.h_in; t.h_off = in.h_off;
+}
+
+int stage_train_inputs(ga3c_net* net, Stage& s, const void* x, bool u8, const float* y_r, const float* a, int B) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   if (x) {
     const size_t xb = (size_t)B * XS * (u8 ? 1 : sizeof(float));
-    void* dst = u8 ? (void*)t.f.xu8 : (void*)t.f.x;
+    void* dst = u8 ? (void*)s.xu8 : (void*)s.x;
     if (is_pinned(x)) {
-      HIPCHK(hipMemcpyAsync(dst, x, xb, hipMemcpyHostToDevice, t.st));
+      HIPCHK(hipMemcpyAsync(dst, x, xb, hipMemcpyHostToDevice, s.st));
     } else {
-      memcpy(t.h_in, x, xb);
-      HIPCHK(hipMemcpyAsync(dst, t.h_in, xb, hipMemcpyHostToDevice, t.st));
+      memcpy(s.h_in, x, xb);
+      HIPCHK(hipMemcpyAsync(dst, s.h_in, xb, hipMemcpyHostToDevice, s.st));
     }
-    t.f.x_u8 = u8;
+    s.x_u8 = u8;
   }
-  float* hy = t.h_in + (size_t)net->maxB * XS;
+  float* hy = s.h_in + (size_t)net->maxB * XS;
   float* ha = hy + net->maxB;
   if (y_r) {
     memcpy(hy, y_r, (size_t)B * sizeof(float));
-    HIPCHK(hipMemcpyAsync(t.yr, hy, (size_t)B * sizeof(float), hipMemcpyHostToDevice, t.st));
+    HIPCHK(hipMemcpyAsync(s.yr, hy, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s.st));
   }
   if (a) {
     memcpy(ha, a, (size_t)B * net->A * sizeof(float));
-    HIPCHK(hipMemcpyAsync(t.act, ha, (size_t)B * net->A * sizeof(float), hipMemcpyHostToDevice, t.st));
+    HIPCHK(hipMemcpyAsync(s.act, ha, (size_t)B * net->A * sizeof(float), hipMemcpyHostToDevice, s.st));
   }
+  return GA3C_OK;
+}
+
+// resident / evaluation callers: stage into the lane's bound buffers on the train stream
+int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, const float* y_r, const float* a, int B) {
+  Stage s = lane_stage(t);
+  CHK(stage_train_inputs(net, s, x, u8, y_r, a, B));
+  t.f.x_u8 = s.x_u8;
   return GA3C_OK;
 }
 
@@ -738,14 +794,14 @@ int stage_offsets(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
 
 // rows of a batch gathered from the registered host segment into x (device), on stream st; the gather kernel reads
 // the offsets out of the pinned host array itself: no H2D copy to wait for
-int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t* h_off, Fwd& f, hipStream_t st) {
-  CHK(stage_offsets(net, offsets, B, u8, h_off));
+int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, Stage& s) {
+  CHK(stage_offsets(net, offsets, B, u8, s.h_off));
   const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, st, net->reg_dev, h_off, f.xu8, B);
-  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, st, net->reg_dev, h_off, f.x, B);
-  f.x_u8 = u8;
+  if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, s.st, net->reg_dev, s.h_off, s.xu8, B);
+  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, s.st, net->reg_dev, s.h_off, s.x, B);
+  s.x_u8 = u8;
   HIPCHK(hipGetLastError());
   return GA3C_OK;
 }
@@ -826,7 +882,9 @@ Lane* take_lane(ga3c_net* net) {
     if (c->mu.try_lock()) return c;
   }
   Lane* L = net->lanes[start % net->lanes.size()];
+  const int64_t t0 = now_ns();
   L->mu.lock();
+  stat_add(net, GA3C_STAT_PREDICT_LANE_WAIT_NS, now_ns() - t0);
   return L;
 }
 
@@ -836,9 +894,15 @@ int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, 
   float* hv = hp + (size_t)net->maxB * A;
   float* hz = hv + net->maxB;
   // the heads kernel stores p and v straight into the lane's pinned host buffer: no D2H copies on the round trip
+  const int64_t t0 = now_ns();
   CHK(lane_forward(net, *L, B, mode, hp, hv));
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
+  const int64_t t1 = now_ns();
   HIPCHK(hipStreamSynchronize(L->st));
+  stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
+  stat_add(net, GA3C_STAT_PREDICT_ROWS, B);
+  stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
+  stat_add(net, GA3C_STAT_PREDICT_SYNC_NS, now_ns() - t1);
   memcpy(p, hp, (size_t)B * A * sizeof(float));
   memcpy(v, hv, (size_t)B * sizeof(float));
   if (z) memcpy(z, hz, (size_t)B * A * sizeof(float));
@@ -874,32 +938,104 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
   return finish_predict(net, L, B, STEP_RESIDENT, p, v, z);
 }
 
-// Lane for one train call.  Synchronous mode: lane 0, callers queue on its mutex.  Hogwild mode: any free lane.
-// Returned locked.
-TrainLane* take_train_lane(ga3c_net* net) {
-  if (!net->hogwild || net->xtr.empty()) {
-    net->tr.mu.lock();
-    return &net->tr;
-  }
+// Lane of a pipelined train call, chosen without locking: lane 0 in synchronous mode, round robin over the Hogwild lanes
+TrainLane* pick_train_lane(ga3c_net* net) {
+  if (!net->hogwild || net->xtr.empty()) return &net->tr;
   const size_t n = net->xtr.size() + 1;
-  const unsigned start = net->trr.fetch_add(1);
-  for (size_t k = 0; k < n; ++k) {
-    const size_t i = (start + k) % n;
-    TrainLane* c = i == 0 ? &net->tr : net->xtr[i - 1];
+  const size_t i = net->trr.fetch_add(1) % n;
+  return i == 0 ? &net->tr : net->xtr[i - 1];
+}
+
+// A free intake of lane t, locked: whichever is not being staged / trained by another thread, else wait for one in turn.
+Intake* take_intake(TrainLane& t) {
+  const unsigned start = t.in_rr.fetch_add(1);
+  for (unsigned k = 0; k < 2; ++k) {
+    Intake* c = &t.in[(start + k) & 1];
     if (c->mu.try_lock()) return c;
   }
-  const size_t i = start % n;
-  TrainLane* c = i == 0 ? &net->tr : net->xtr[i - 1];
+  Intake* c = &t.in[start & 1];
   c->mu.lock();
   return c;
+}
+
+// Resident / development entry points work on lane t's bound buffers directly: nobody may be staging into them meanwhile.
+struct ResidentHold {
+  TrainLane& t;
+  explicit ResidentHold(TrainLane& lane) : t(lane) {
+    t.in[0].mu.lock();
+    t.in[1].mu.lock();
+    t.mu.lock();
+  }
+  ~ResidentHold() {
+    t.mu.unlock();
+    t.in[1].mu.unlock();
+    t.in[0].mu.unlock();
+  }
+  ResidentHold(const ResidentHold&) = delete;
+  ResidentHold& operator=(const ResidentHold&) = delete;
+};
+
+// One call on a batch that arrives from outside: `stage` puts it into a free intake on the lane's staging stream (the
+// calling thread owns that intake for the whole call); then, in the lane's turn, `body` runs with the intake bound to the
+// lane and the train stream ordered behind the staging.  While one thread is inside `body` (a step in flight), the next
+// thread's `stage` -- the PCIe gather of its rows -- proceeds on the staging stream.
+template <class StageFn, class BodyFn>
+int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body) {
+  if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  TrainLane* t = pick_train_lane(net);
+  const int64_t t0 = now_ns();
+  Intake* in = take_intake(*t);
+  std::lock_guard<std::mutex> ig(in->mu, std::adopt_lock);
+  Stage s = intake_stage(*t, *in);
+  CHK(stage(s));
+  in->x_u8 = s.x_u8;
+  HIPCHK(hipEventRecord(in->ready, t->gst));
+  const int64_t t1 = now_ns();
+  std::lock_guard<std::mutex> tl(t->mu);
+  const int64_t t2 = now_ns();
+  bind_intake(*t, *in);
+  HIPCHK(hipStreamWaitEvent(t->st, in->ready, 0));
+  stat_add(net, GA3C_STAT_TRAIN_STAGE_NS, t1 - t0);
+  stat_add(net, GA3C_STAT_TRAIN_LANE_WAIT_NS, t2 - t1);
+  return body(*t);
+}
+
+// the body of every train entry point: forward, backward, update, then wait for the step and hand back its losses
+int train_body(ga3c_net* net, TrainLane& t, int B, float lr, float beta, float* losses) {
+  const int64_t t0 = now_ns();
+  CHK(train_grads(net, t, B, beta, true, lr));
+  CHK(train_apply(net, t, lr));
+  const int64_t t1 = now_ns();
+  const int rc = read_losses(net, t, losses);
+  stat_add(net, GA3C_STAT_TRAIN_CALLS, 1);
+  stat_add(net, GA3C_STAT_TRAIN_ROWS, B);
+  stat_add(net, GA3C_STAT_TRAIN_LAUNCH_NS, t1 - t0);
+  stat_add(net, GA3C_STAT_TRAIN_SYNC_NS, now_ns() - t1);
+  return rc;
 }
 
 int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
   const int maxB = net->maxB, A = net->A;
   HIPCHK(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&t.gst, hipStreamNonBlocking));
   CHK(alloc_fwd(t.f, maxB, A));
-  CHK(dmalloc(&t.yr, maxB));
-  CHK(dmalloc(&t.act, (size_t)maxB * A));
+  for (int k = 0; k < 2; ++k) {
+    Intake& in = t.in[k];
+    if (k == 0) {                      // intake 0 takes over the x buffers alloc_fwd made
+      in.x = t.f.x;
+      in.xu8 = t.f.xu8;
+    } else {
+      CHK(dmalloc(&in.x, (size_t)maxB * XS));
+      HIPCHK(hipMalloc((void**)&in.xu8, (size_t)maxB * XS));
+    }
+    CHK(dmalloc(&in.yr, maxB));
+    CHK(dmalloc(&in.act, (size_t)maxB * A));
+    HIPCHK(hipHostMalloc((void**)&in.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&in.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&in.ready, hipEventDisableTiming));
+  }
+  bind_intake(t, t.in[0]);
   CHK(dmalloc(&t.dz, (size_t)maxB * A));
   CHK(dmalloc(&t.dv, maxB));
   CHK(dmalloc(&t.lossrow, (size_t)maxB * 3));
@@ -916,22 +1052,35 @@ int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
     CHK(dmalloc(&t.grad, (size_t)net->n));
     t.owns_grad = true;
   }
-  HIPCHK(hipHostMalloc((void**)&t.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&t.h_out, ((size_t)maxB * (2 * A + 1) + 4) * sizeof(float), hipHostMallocDefault));
   HIPCHK(hipEventCreate(&t.ev0));
   HIPCHK(hipEventCreate(&t.ev1));
-  HIPCHK(hipHostMalloc((void**)&t.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
   return GA3C_OK;
 }
 
 void free_train_lane(TrainLane& t) {
+  if (!t.in[0].x && !t.in[0].xu8) {    // allocation failed before intake 0 took alloc_fwd's x buffers over
+    if (t.f.x) (void)hipFree(t.f.x);
+    if (t.f.xu8) (void)hipFree(t.f.xu8);
+  }
+  for (Intake& in : t.in) {            // the x buffers, y / a and the pinned arrays belong to the intakes
+    if (in.x) (void)hipFree(in.x);
+    if (in.xu8) (void)hipFree(in.xu8);
+    if (in.yr) (void)hipFree(in.yr);
+    if (in.act) (void)hipFree(in.act);
+    if (in.h_in) (void)hipHostFree(in.h_in);
+    if (in.h_off) (void)hipHostFree(in.h_off);
+    if (in.ready) (void)hipEventDestroy(in.ready);
+    in.x = nullptr; in.xu8 = nullptr;
+  }
+  t.f.x = nullptr;
+  t.f.xu8 = nullptr;
   free_fwd(t.f);
-  for (float* p : {t.yr, t.act, t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.losses, t.scales})
+  for (float* p : {t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.losses, t.scales})
     if (p) (void)hipFree(p);
   if (t.owns_grad && t.grad) (void)hipFree(t.grad);
-  if (t.h_in) (void)hipHostFree(t.h_in);
   if (t.h_out) (void)hipHostFree(t.h_out);
-  if (t.h_off) (void)hipHostFree(t.h_off);
+  if (t.gst) (void)hipStreamDestroy(t.gst);
   if (t.ev0) (void)hipEventDestroy(t.ev0);
   if (t.ev1) (void)hipEventDestroy(t.ev1);
   if (t.st) (void)hipStreamDestroy(t.st);
@@ -1031,6 +1180,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   ga3c_net* net = new (std::nothrow) ga3c_net();
   if (!net) return fail(GA3C_EINVAL, "out of host memory");
   net->cfg = *cfg;
+  for (auto& c : net->stat) c.store(0);
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
@@ -1260,7 +1410,7 @@ int ga3c_net_compute_grads(ga3c_net* net, const float* x, const float* y_r, cons
                            float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
+  ResidentHold hold(net->tr);
   CHK(stage_train_inputs(net, net->tr, x, false, y_r, a, batch));
   CHK(train_grads(net, net->tr, batch, beta));
   return read_losses(net, net->tr, losses);
@@ -1278,25 +1428,15 @@ int ga3c_net_apply_grads(ga3c_net* net, float learning_rate) {
 int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch,
                    float learning_rate, float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(net->cfg.device));
-  TrainLane* t = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
-  CHK(stage_train_inputs(net, *t, x, false, y_r, a, batch));
-  CHK(train_grads(net, *t, batch, beta, true, learning_rate));
-  CHK(train_apply(net, *t, learning_rate));
-  return read_losses(net, *t, losses);
+  return with_staged_batch(net, batch, [&](Stage& s) { return stage_train_inputs(net, s, x, false, y_r, a, batch); },
+                           [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
 }
 
 int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch,
                       float learning_rate, float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(net->cfg.device));
-  TrainLane* t = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
-  CHK(stage_train_inputs(net, *t, x, true, y_r, a, batch));
-  CHK(train_grads(net, *t, batch, beta, true, learning_rate));
-  CHK(train_apply(net, *t, learning_rate));
-  return read_losses(net, *t, losses);
+  return with_staged_batch(net, batch, [&](Stage& s) { return stage_train_inputs(net, s, x, true, y_r, a, batch); },
+                           [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
 }
 
 int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const int64_t* offsets, int32_t offsets_u8,
@@ -1305,17 +1445,16 @@ int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const 
   if (!net || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   if ((x != nullptr) + (x_u8 != nullptr) + (offsets != nullptr) != 1)
     return fail(GA3C_EINVAL, "evaluate: exactly one of x, x_u8, offsets names the states");
-  HIPCHK(hipSetDevice(net->cfg.device));
-  TrainLane* tp = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
-  TrainLane& t = *tp;
-  if (offsets) {
-    CHK(launch_gather(net, offsets, batch, offsets_u8 != 0, t.h_off, t.f, t.st));
-    CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
-  } else {
-    CHK(stage_train_inputs(net, t, x ? (const void*)x : (const void*)x_u8, x == nullptr, y_r, a, batch));
-  }
-  return evaluate_staged(net, t, batch, beta, losses, d1, v, p);
+  return with_staged_batch(
+      net, batch,
+      [&](Stage& s) {
+        if (offsets) {
+          CHK(launch_gather(net, offsets, batch, offsets_u8 != 0, s));
+          return stage_train_inputs(net, s, nullptr, false, y_r, a, batch);
+        }
+        return stage_train_inputs(net, s, x ? (const void*)x : (const void*)x_u8, x == nullptr, y_r, a, batch);
+      },
+      [&](TrainLane& t) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); });
 }
 
 int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes) {
@@ -1363,15 +1502,13 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
 int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses) {
   if (!net || !offsets || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
-  HIPCHK(hipSetDevice(net->cfg.device));
-  TrainLane* tp = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
-  TrainLane& t = *tp;
-  CHK(launch_gather(net, offsets, batch, u8 != 0, t.h_off, t.f, t.st));
-  CHK(stage_train_inputs(net, t, nullptr, false, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta, true, learning_rate));
-  CHK(train_apply(net, t, learning_rate));
-  return read_losses(net, t, losses);
+  return with_staged_batch(
+      net, batch,
+      [&](Stage& s) {
+        CHK(launch_gather(net, offsets, batch, u8 != 0, s));
+        return stage_train_inputs(net, s, nullptr, false, y_r, a, batch);
+      },
+      [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
 }
 
 // ---- frame front-end ------------------------------------------------------------------------------------------
@@ -1587,8 +1724,14 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   const int A = net->A;
   float* hp = L->h_out;
   float* hv = hp + (size_t)net->maxB * A;
+  const int64_t t0 = now_ns();
   CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
+  const int64_t t1 = now_ns();
   HIPCHK(hipStreamSynchronize(L->st));
+  stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
+  stat_add(net, GA3C_STAT_PREDICT_ROWS, want);
+  stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
+  stat_add(net, GA3C_STAT_PREDICT_SYNC_NS, now_ns() - t1);
   for (int i = 0, k = 0; i < n; ++i) {
     if (flags[i] & 2u) continue;
     memcpy(p + (size_t)i * A, hp + (size_t)k * A, (size_t)A * sizeof(float));
@@ -1598,7 +1741,7 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
 }
 
 // rows named by (agent, plane sequence number) re-assembled from the plane history into train lane `t` (its mutex held)
-static int stage_history_rows(ga3c_net* net, TrainLane& t, const int32_t* agents, const int64_t* seqs, const float* y_r,
+static int stage_history_rows(ga3c_net* net, Stage& s, const int32_t* agents, const int64_t* seqs, const float* y_r,
                               const float* a, int32_t batch);
 
 int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
@@ -1606,14 +1749,8 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
   if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
-  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
-  TrainLane* tp = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
-  TrainLane& t = *tp;
-  CHK(stage_history_rows(net, t, agents, seqs, y_r, a, batch));
-  CHK(train_grads(net, t, batch, beta, true, learning_rate));
-  CHK(train_apply(net, t, learning_rate));
-  return read_losses(net, t, losses);
+  return with_staged_batch(net, batch, [&](Stage& s) { return stage_history_rows(net, s, agents, seqs, y_r, a, batch); },
+                           [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
 }
 
 int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
@@ -1621,11 +1758,8 @@ int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t
   if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
   if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
-  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
-  TrainLane* tp = take_train_lane(net);
-  std::lock_guard<std::mutex> tl(tp->mu, std::adopt_lock);
-  CHK(stage_history_rows(net, *tp, agents, seqs, y_r, a, batch));
-  return evaluate_staged(net, *tp, batch, beta, losses, d1, v, p);
+  return with_staged_batch(net, batch, [&](Stage& s) { return stage_history_rows(net, s, agents, seqs, y_r, a, batch); },
+                           [&](TrainLane& t) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); });
 }
 
 int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed) {
@@ -1638,7 +1772,7 @@ int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed) {
   return GA3C_OK;
 }
 
-static int stage_history_rows(ga3c_net* net, TrainLane& t, const int32_t* agents, const int64_t* seqs, const float* y_r,
+static int stage_history_rows(ga3c_net* net, Stage& s, const int32_t* agents, const int64_t* seqs, const float* y_r,
                               const float* a, int32_t batch) {
   Frames& f = net->fr;
   {
@@ -1653,16 +1787,16 @@ static int stage_history_rows(ga3c_net* net, TrainLane& t, const int32_t* agents
     }
   }
   // the row descriptors ride in the lane's pinned offset array: seqs first, agent ids behind them
-  int64_t* h_seq = t.h_off;
-  int32_t* h_ag = reinterpret_cast<int32_t*>(t.h_in);
+  int64_t* h_seq = s.h_off;
+  int32_t* h_ag = reinterpret_cast<int32_t*>(s.h_in);
   for (int i = 0; i < batch; ++i) { h_seq[i] = seqs[i]; h_ag[i] = agents[i]; }
   const int64_t total = (int64_t)batch * (IMG * IMG / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, t.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, t.f.xu8, batch);
+  hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, s.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, s.xu8, batch);
   HIPCHK(hipGetLastError());
-  t.f.x_u8 = true;   // (y_r and a are staged behind the x region of h_in: the ids at its start stay untouched)
-  return stage_train_inputs(net, t, nullptr, false, y_r, a, batch);
+  s.x_u8 = true;   // (y_r and a are staged behind the x region of h_in: the ids at its start stay untouched)
+  return stage_train_inputs(net, s, nullptr, false, y_r, a, batch);
 }
 
 int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n) {
@@ -1702,7 +1836,7 @@ int ga3c_net_time_frames(ga3c_net* net, int32_t n, int32_t iters, float* elapsed
 int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float* a, int32_t batch) {
   if (!net || !x) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
+  ResidentHold hold(net->tr);
   CHK(stage_train_inputs(net, net->tr, x, false, y_r, a, batch));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
@@ -1711,7 +1845,7 @@ int ga3c_net_upload(ga3c_net* net, const float* x, const float* y_r, const float
 int ga3c_net_upload_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch) {
   if (!net || !x) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
+  ResidentHold hold(net->tr);
   CHK(stage_train_inputs(net, net->tr, x, true, y_r, a, batch));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   return GA3C_OK;
@@ -1776,7 +1910,7 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   if (iters < 1 || nlanes < 1 || nlanes > (int)net->lanes.size()) return fail(GA3C_EINVAL, "bad iters/nlanes");
   if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "bad batch");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
+  ResidentHold hold(net->tr);
   CHK(sync_all(net));
   for (int l = 0; l < nlanes; ++l) {
     Fwd& lf = net->lanes[l]->f;
@@ -1837,7 +1971,7 @@ int ga3c_net_time_train_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32
   if (nlanes > 1 && !net->hogwild) return fail(GA3C_ESTATE, "net was not created with train_lanes >= 2");
   if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "bad batch");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
+  ResidentHold hold(net->tr);
   CHK(sync_all(net));
   TrainLane& t0 = net->tr;
   for (int l = 1; l < nlanes; ++l) {
@@ -1985,7 +2119,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
 int ga3c_net_fetch(ga3c_net* net, const char* name, float* out, int64_t count) {
   if (!net || !name || !out) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
-  std::lock_guard<std::mutex> tl(net->tr.mu);
+  ResidentHold hold(net->tr);
   TrainLane& t = net->tr;
   const int64_t B = net->maxB, A = net->A;
   struct Ent { const char* n; const float* p; int64_t cap; };
@@ -2038,6 +2172,14 @@ int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int3
   HIPCHK(hipStreamCreateWithFlags(&net->cst, hipStreamNonBlocking));
   for (hipEvent_t* e : {&net->ev_tail_ready, &net->ev_head_ready, &net->ev_comm_done})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  return GA3C_OK;
+}
+
+int ga3c_net_stats(ga3c_net* net, int64_t* out, int32_t n, int32_t reset) {
+  if (!net || !out || n < 0) return fail(GA3C_EINVAL, "bad argument");
+  for (int i = 0; i < n && i < GA3C_STAT_COUNT; ++i)
+    out[i] = reset ? net->stat[i].exchange(0, std::memory_order_relaxed) : net->stat[i].load(std::memory_order_relaxed);
+  for (int i = GA3C_STAT_COUNT; i < n; ++i) out[i] = 0;
   return GA3C_OK;
 }
 

@@ -195,6 +195,27 @@ int ga3c_net_time_frames(ga3c_net* net, int32_t n, int32_t iters, float* elapsed
 int ga3c_host_alloc(void** ptr, int64_t bytes);
 int ga3c_host_free(void* ptr);
 
+/* Where the calls of a running engine spend their time (no counterpart in the reference; tools/e2e_probe.py and the
+ * engine legs of bench.py print the deltas).  out[i] for i < n, i < GA3C_STAT_COUNT; times in nanoseconds since the
+ * net was created (or since the last call with reset != 0). */
+enum {
+  GA3C_STAT_PREDICT_CALLS = 0,     /* prediction calls (predict, predict_gather, predict_frames, serve_frames) */
+  GA3C_STAT_PREDICT_ROWS,          /* rows they carried */
+  GA3C_STAT_PREDICT_LANE_WAIT_NS,  /* waiting for a free prediction lane */
+  GA3C_STAT_PREDICT_LAUNCH_NS,     /* host time to enqueue a step */
+  GA3C_STAT_PREDICT_SYNC_NS,       /* from the last launch to the lane's stream being idle (GPU time + queueing) */
+  GA3C_STAT_PREDICT_WEIGHT_WAITS,  /* steps that had to wait on the GPU for an optimizer step in flight (theta_ready) */
+  GA3C_STAT_TRAIN_CALLS,           /* train calls */
+  GA3C_STAT_TRAIN_ROWS,
+  GA3C_STAT_TRAIN_STAGE_NS,        /* staging a batch into an intake: offsets, gather launch, y / a copies (host time) */
+  GA3C_STAT_TRAIN_LANE_WAIT_NS,    /* waiting for the train lane (another thread's step) with the batch already staged */
+  GA3C_STAT_TRAIN_LAUNCH_NS,       /* host time to enqueue forward + backward + update */
+  GA3C_STAT_TRAIN_SYNC_NS,         /* from the last launch to the step's completion */
+  GA3C_STAT_TRAIN_READER_WAITS,    /* cross-stream waits a step issued for prediction lanes still reading the buffer it overwrites */
+  GA3C_STAT_COUNT
+};
+int ga3c_net_stats(ga3c_net* net, int64_t* out, int32_t n, int32_t reset);
+
 /* Data-parallel training over RCCL (no counterpart in the reference, which is
  * single-device: Config.py:62).  id is an opaque 128-byte token made on rank 0 and
  * handed to every rank by the launcher.  After comm_init, train and apply_grads

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--linger-us", type=int, default=0)
     ap.add_argument("--linger-batch", type=int, default=0)
     ap.add_argument("--dynamic", action="store_true", help="ThreadDynamicAdjustment random walk every 2 s (soak test)")
+    ap.add_argument("--lanes", type=int, default=0, help="prediction lanes of the Network (0: one per predictor, the default)")
     ap.add_argument("--frames", choices=["planes", "planes-device", "rgb-host", "rgb-device"], default="planes",
                     help="frame source / where the reference's front-end runs (Config.FRAME_SOURCE, Config.FRONTEND)")
     args = ap.parse_args()
@@ -60,8 +61,17 @@ def main():
     Config.RESULTS_FILENAME = "/tmp/e2e_probe_results.txt"
     Config.EPISODES = 10 ** 9
 
+    if args.lanes:
+        os.environ["GA3C_PREDICT_LANES"] = str(args.lanes)
     srv = Server(max_agents=args.agents)
     me = psutil.Process()
+
+    def cgroup():
+        try:
+            d = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+            return int(d.get("usage_usec", 0)), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+        except OSError:
+            return 0, 0, 0
     snap = {}
 
     def cpu_of(procs):
@@ -79,6 +89,7 @@ def main():
         return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step,
                 "batches": sum(p.batches for p in srv.predictors),
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")}, "srv_cpu": cpu_of([me]), "agent_cpu": cpu_of(kids),
+                "cg": cgroup(), "eng": srv.model.stats() if hasattr(srv.model, "stats") else {},
                 "n_kids": len(kids), "n_agents": len(srv.agents), "alive": sum(1 for a in srv.agents if a.is_alive()), "n_pred": len(srv.predictors), "n_train": len(srv.trainers),
                 "rss_mb": round(me.memory_info().rss / 2 ** 20), "spills": sum(t.spills for t in srv.trainers), "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive())}
 
@@ -98,7 +109,17 @@ def main():
         return
     dt = b["t"] - a["t"]
     pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
+    eng = {k: b["eng"].get(k, 0) - a["eng"].get(k, 0) for k in b["eng"]}
+    pc, tc = max(eng.get("predict_calls", 0), 1), max(eng.get("train_calls", 0), 1)
+    engine = {"predict_us_per_call": {k[8:-3]: round(eng[k] / pc / 1e3, 1) for k in eng if k.startswith("predict_") and k.endswith("_ns")},
+              "predict_weight_waits_per_call": round(eng.get("predict_weight_waits", 0) / pc, 3),
+              "train_us_per_call": {k[6:-3]: round(eng[k] / tc / 1e3, 1) for k in eng if k.startswith("train_") and k.endswith("_ns")},
+              "train_reader_waits_per_call": round(eng.get("train_reader_waits", 0) / tc, 3),
+              "train_rows_per_call": round(eng.get("train_rows", 0) / tc, 1)}
     print(json.dumps({
+        "lanes": args.lanes or args.predictors, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "engine": engine,
+        "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / (b["t"] - a["t"]), 2), "throttled_periods": b["cg"][1] - a["cg"][1],
+                   "throttled_s": round((b["cg"][2] - a["cg"][2]) / 1e6, 2)},
         "agents": args.agents, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
         "hogwild": bool(args.hogwild), "frames": args.frames, "linger": [args.linger_us, args.linger_batch], "native_predictor": not args.python_predictor, "window_s": round(dt, 2), "host_cores": os.cpu_count(),
         "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),

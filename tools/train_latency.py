@@ -1,9 +1,11 @@
 """Latency of one synchronous train call through the C ABI (development aid): rows gathered out of the registered transport
-segment (the zero-copy trainer path) against the same batch resident in HBM.
+segment (the zero-copy trainer path) against the same batch resident in HBM -- from ONE calling thread, and from TWO
+(Config.TRAINERS = 2, Server.py:132-134): the second thread's gather runs on the lane's staging stream while the first
+thread's step is in flight, so the time per call is what the slower of the two phases takes.
 
     python tools/train_latency.py [batch ...]
 """
-import os, sys, time
+import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ga3c_amd, Transport as tp
@@ -27,11 +29,33 @@ for n in batches:
     for _ in range(300):
         net.train_offsets(offs, y, a)
     call = (time.perf_counter() - t0) / 300 * 1e6
+    # two trainer threads, each with rows of its own (the GIL is released inside the ctypes call)
+    offs2 = t.state_offsets(np.arange(160 - n, 160, dtype=np.uint32)) if n <= 80 else offs
+    go = threading.Barrier(3)
+
+    def trainer(o_):
+        go.wait()
+        for _ in range(300):
+            net.train_offsets(o_, y, a)
+        go.wait()
+    ths = [threading.Thread(target=trainer, args=(o_,)) for o_ in (offs, offs2)]
+    for th in ths:
+        th.start()
+    net.stats(reset=True)
+    go.wait()
+    t0 = time.perf_counter()
+    go.wait()
+    call2 = (time.perf_counter() - t0) / 600 * 1e6
+    st = net.stats()
+    for th in ths:
+        th.join()
+    split = {k: round(st[k] / max(st["train_calls"], 1) / 1e3, 1) for k in ("train_stage_ns", "train_lane_wait_ns", "train_launch_ns", "train_sync_ns")}
     xk = np.ascontiguousarray(t.agent_states[:n]).reshape(n, 84, 84, 4)
     nat.check(net._lib.ga3c_net_upload_u8(net._h, nat.ptr(xk, nat.u8p), nat.ptr(y), nat.ptr(a), n))
     ms = nat.C.c_float()
     nat.check(net._lib.ga3c_net_time_resident(net._h, 1, n, 300, 3e-4, 0.01, nat.C.byref(ms)))
-    print("batch %3d: synchronous train_offsets call %6.1f us; resident, pipelined %5.1f us per step" % (n, call, ms.value / 300 * 1e3))
+    print("batch %3d: synchronous train_offsets call %6.1f us from one thread, %6.1f us per call from two threads "
+          "(us per call: %s); resident, back to back %5.1f us per step" % (n, call, call2, split, ms.value / 300 * 1e3))
 net.unregister_transport()
 # rows named by (agent, plane) out of the device-side plane history (frame queue on the device)
 net.frames_config(160, 84, 84, 1, history=16)
