@@ -209,36 +209,43 @@ def main():
         torch.cuda.synchronize()
 
     def timed_block(mode, steps, lanes=0, rows=None):
-        """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks of the wall time."""
-        ev_ms = nat.C.c_float()
+        """EXACTLY `steps` steps between barrier + synchronize on both sides.  Returns (GPU span, host wall), both in
+        seconds and both the max over ranks.  GPU span = HIP events on the streams the steps run on: first start event to
+        last end event of the block (ga3c_net_last_lanes_gpu_ms; the train stream's own event pair for the train leg).
+        The host wall clock around the same block also contains the launch latency of the block's first kernel, the
+        wake-up of the synchronising host threads and the Python / ctypes / torch.cuda.synchronize() calls: ~50 us, a
+        seventh of a 20-step block of this path and nothing of a 300-step one."""
+        ev_ms, gpu_ms = nat.C.c_float(), nat.C.c_float()
         rows = B if rows is None else rows
         barrier_sync()
         t0 = time.perf_counter()
         if lanes:
             nat.check(lib.ga3c_net_time_predict_lanes(h, rows, steps, lanes, nat.C.byref(ev_ms)), "time_predict_lanes")
+            nat.check(lib.ga3c_net_last_lanes_gpu_ms(h, nat.C.byref(gpu_ms)), "last_lanes_gpu_ms")
         else:
-            nat.check(lib.ga3c_net_time_resident(h, mode, rows, steps, lr, beta, nat.C.byref(ev_ms)), "time_resident")
+            nat.check(lib.ga3c_net_time_resident(h, mode, rows, steps, lr, beta, nat.C.byref(gpu_ms)), "time_resident")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        gpu_s, wall_s = gpu_ms.value * 1e-3, t1 - t0
         if world > 1:
             dist.barrier()
-            tmax = torch.tensor([t1 - t0], dtype=torch.float64)
+            tmax = torch.tensor([gpu_s, wall_s], dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            return float(tmax[0]), ev_ms.value
-        return t1 - t0, ev_ms.value
+            gpu_s, wall_s = float(tmax[0]), float(tmax[1])
+        return gpu_s, wall_s
 
     MIN_TIMED_S, MAX_BLOCKS = 0.05, 400
     blocks_used = {}
 
     def timed(mode, steps, lanes=0, tag=None, rows=None):
-        """A K-step block of this path lasts well under a millisecond at the driver's K = 20, which is mostly the start-up
-        of the streams: the bracketed K-step block is repeated until at least 50 ms have been timed and the MEDIAN block
-        is reported (every rank runs the same number of blocks: the count is decided on rank 0's clock)."""
-        walls, evs, total = [], [], 0.0
+        """A K-step block of this path lasts well under a millisecond at the driver's K = 20: the bracketed K-step block is
+        repeated until at least 50 ms have been timed and the MEDIAN block is reported (every rank runs the same number
+        of blocks: the count is decided on rank 0's clock).  Returns (median GPU span, median host wall) in seconds."""
+        gpus, walls, total = [], [], 0.0
         while True:
-            w, e = timed_block(mode, steps, lanes, rows)
+            g, w = timed_block(mode, steps, lanes, rows)
+            gpus.append(g)
             walls.append(w)
-            evs.append(e)
             total += w
             more = 1 if (total < MIN_TIMED_S and len(walls) < MAX_BLOCKS) else 0
             if world > 1:
@@ -249,7 +256,7 @@ def main():
                 break
         if tag:
             blocks_used[tag] = len(walls)
-        return float(np.median(walls)), float(np.median(evs))
+        return float(np.median(gpus)), float(np.median(walls))
 
     ev_ms = nat.C.c_float()
     for mode in (0, 1):
@@ -262,8 +269,8 @@ def main():
         net.close()
         print(json.dumps(dict(res, hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES"))))
         return
-    pred_s, pred_inner_ms = timed(0, K, lanes=NP, tag="predict")
-    one_s, pred_ev_ms = timed(0, K)
+    pred_s, pred_wall_s = timed(0, K, lanes=NP, tag="predict")
+    one_s, _ = timed(0, K, lanes=1)
     sweep = {}
     if not args.no_lane_sweep:
         for nl in (2, 3, 4):
@@ -292,10 +299,10 @@ def main():
         dp_guard.daemon = True
         dp_guard.start()
     if dp_error is None:
-        train_s, train_ev_ms = timed(1, K, tag="train")
+        train_s, train_wall_s = timed(1, K, tag="train")
         train_tb_s, _ = timed(1, K, rows=TB)            # what the engine's trainers really assemble at MIN = B - 1
     else:                                               # no communicator: the data-parallel train leg is not measured
-        train_s, train_ev_ms, train_tb_s = None, None, None
+        train_s, train_wall_s, train_tb_s = None, None, None
     allreduce_us = None
     if world > 1 and dp_error is None:      # the exchange step alone: 4.02 MB f32 sum all-reduce, events on the train stream
         barrier_sync()
@@ -329,8 +336,13 @@ def main():
                                   **{str(nl): world * K * B / s_ for nl, s_ in sweep.items()},
                                   unit="predictions/s", hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                                   note="same K steps dealt to 1 .. 4 prediction lanes (one persistent host thread per lane); "
-                                       "`value` is the NP = %d figure, the default of the reference and of this package" % NP),
-            "ms_per_step_inner": pred_inner_ms / K,
+                                       "`value` is the NP = %d figure, the default of the reference and of this package; lanes "
+                                       "beyond two share the two prediction streams (ga3c_net_create: the engine keeps to "
+                                       "four busy streams)" % NP),
+            "ms_per_step_wall": pred_wall_s / K * 1e3,
+            "timing": "ms_per_step / value: GPU span of the median K-step block (HIP events on the lanes' streams, first start "
+                      "to last end, max over ranks); ms_per_step_wall: host clock around the same block between the two "
+                      "device synchronisations (adds ~50 us per block of launch latency, thread wake-up and Python calls)",
             "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
                       "ms_per_step": train_s / K * 1e3 if train_s else None, "rows_per_step": world * B,
                       "trained_samples_per_sec": world * K * B / train_s if train_s else None,
@@ -340,7 +352,7 @@ def main():
                                          "steps_per_sec": K / train_tb_s if train_tb_s else None,
                                          "note": "the largest batch ThreadTrainer assembles at TRAINING_MIN_BATCH_SIZE = %d "
                                                  "(ThreadTrainer.py:49-59): MIN + TIME_MAX rows" % (B - 1)}},
-            "stream_ms_per_step": {"predict": pred_ev_ms / K, "train": train_ev_ms / K if train_ev_ms else None},
+            "wall_ms_per_step": {"predict": pred_wall_s / K * 1e3, "train": train_wall_s / K * 1e3 if train_wall_s else None},
             "timed_blocks": dict(blocks_used, min_timed_ms=MIN_TIMED_S * 1e3,
                                  note="the bracketed K-step block is repeated until >= 50 ms are timed; ms_per_step and "
                                       "value are those of the MEDIAN block"),
@@ -447,11 +459,12 @@ def main():
         try:
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--lanes-only", "--steps", str(max(K, 100)),
                                     "--warmup", str(max(W, 10)), "--batch", str(B), "--actions", str(A)],
-                                   env=dict(os.environ, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True, timeout=240)
+                                   env=dict(os.environ, GPU_MAX_HW_QUEUES="8", GA3C_LANE_STREAMS="4"), capture_output=True, text=True, timeout=240)
             line = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
             out["predict_lanes_8_hw_queues"] = dict(json.loads(line[-1]), unit="predictions/s",
-                                                    note="child process with GPU_MAX_HW_QUEUES=8 (a queue per lane): an "
-                                                         "extra, not the product's configuration") if line else \
+                                                    note="child process with GPU_MAX_HW_QUEUES=8 and GA3C_LANE_STREAMS=4 (a stream "
+                                                         "and a hardware queue per lane, nothing else running): an extra, not "
+                                                         "the product's configuration") if line else \
                 {"error": "child printed no line (rc %d): %s" % (child.returncode, child.stderr[-300:])}
         except (subprocess.TimeoutExpired, OSError, ValueError) as e:
             out["predict_lanes_8_hw_queues"] = {"error": repr(e)}

@@ -91,6 +91,7 @@ HIP_SIGNATURES = {
     "ga3c_host_free": (C.c_int, [C.c_void_p]),
     "ga3c_comm_make_id": (C.c_int, [u8p]),
     "ga3c_net_comm_init": (C.c_int, [C.c_void_p, u8p, C.c_int32, C.c_int32]),
+    "ga3c_net_last_lanes_gpu_ms": (C.c_int, [C.c_void_p, f32p]),
     "ga3c_net_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32]),
     "ga3c_net_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ga3c_net_allreduce_grads": (C.c_int, [C.c_void_p]),

@@ -83,7 +83,11 @@ struct Fwd {   // forward workspace of one lane (device pointers)
 
 struct Lane {
   std::mutex mu;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;   // lanes beyond net->lane_streams borrow the stream of lane (index % lane_streams): see ga3c_net_create
+  bool owns_st = true;
+  bool shared_st = false;     // another lane enqueues on `st` too: completion is waited for on `done`, not on the stream
+  hipEvent_t done = nullptr;
+  hipEvent_t tm0 = nullptr, tm1 = nullptr;   // timing events of ga3c_net_time_predict_lanes
   Fwd f;
   float* h_in = nullptr;    // pinned staging, max_batch states
   float* h_out = nullptr;   // pinned staging, p|v|z
@@ -257,6 +261,8 @@ struct ga3c_net {
   Frames fr;
   TensorTable tt;
   LaneDrivers drv;
+  float lanes_gpu_ms = 0.f;            // GPU-side span of the last ga3c_net_time_predict_lanes block (first start event .. last end event)
+  int lane_streams = 2;                // HIP streams the prediction lanes are spread over (GA3C_LANE_STREAMS)
   // where the engine's calls spend their time (ga3c_net_stats): nanoseconds / counts, relaxed atomics
   std::atomic<int64_t> stat[GA3C_STAT_COUNT];
 };
@@ -513,11 +519,8 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
       L.f.src_base = base;
       L.f.src_off = L.h_off;
     } else {
-      const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
-      int blocks = (int)((total + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.xu8, B);
-      else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, L.st, base, L.h_off, L.f.x, B);
+      if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.xu8), B);
+      else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B);
     }
   }
   const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
@@ -796,11 +799,8 @@ int stage_offsets(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
 // the offsets out of the pinned host array itself: no H2D copy to wait for
 int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, Stage& s) {
   CHK(stage_offsets(net, offsets, B, u8, s.h_off));
-  const int64_t total = (int64_t)B * (u8 ? XS / 16 : XS / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  if (u8) hipLaunchKernelGGL(gather_u8_kernel, dim3(blocks), dim3(256), 0, s.st, net->reg_dev, s.h_off, s.xu8, B);
-  else hipLaunchKernelGGL(gather_states_kernel<false>, dim3(blocks), dim3(256), 0, s.st, net->reg_dev, s.h_off, s.x, B);
+  if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.xu8), B);
+  else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.x), B);
   s.x_u8 = u8;
   HIPCHK(hipGetLastError());
   return GA3C_OK;
@@ -888,6 +888,17 @@ Lane* take_lane(ga3c_net* net) {
   return L;
 }
 
+// wait until everything lane L has enqueued is done (L's mutex is held)
+int lane_wait(Lane* L) {
+  if (!L->shared_st) {
+    HIPCHK(hipStreamSynchronize(L->st));
+    return GA3C_OK;
+  }
+  HIPCHK(hipEventRecord(L->done, L->st));
+  HIPCHK(hipEventSynchronize(L->done));
+  return GA3C_OK;
+}
+
 int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, float* z) {
   const int A = net->A;
   float* hp = L->h_out;
@@ -898,7 +909,7 @@ int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, 
   CHK(lane_forward(net, *L, B, mode, hp, hv));
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
   const int64_t t1 = now_ns();
-  HIPCHK(hipStreamSynchronize(L->st));
+  CHK(lane_wait(L));
   stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
   stat_add(net, GA3C_STAT_PREDICT_ROWS, B);
   stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
@@ -1120,13 +1131,16 @@ void lane_driver_main(ga3c_net* net, int l) {
       d.errs[l] = "hipSetDevice failed on the lane's driver thread";
     } else {
       PredictInFlight inflight(net);
+      (void)hipEventRecord(L->tm0, L->st);
       for (int i = l; i < iters; i += nlanes) {                  // lane l takes the steps l, l + nlanes, ...
         const int rc = lane_step(net, *L, idx, batch, STEP_RESIDENT, nullptr, nullptr);
         if (rc != GA3C_OK) { d.rcs[l] = rc; d.errs[l] = g_err; break; }
       }
-      if (hipStreamSynchronize(L->st) != hipSuccess && d.rcs[l] == GA3C_OK) {
-        d.rcs[l] = GA3C_EHIP;
-        d.errs[l] = "hipStreamSynchronize failed";
+      if (hipEventRecord(L->tm1, L->st) != hipSuccess || hipEventSynchronize(L->tm1) != hipSuccess) {
+        if (d.rcs[l] == GA3C_OK) {
+          d.rcs[l] = GA3C_EHIP;
+          d.errs[l] = "waiting for the lane's last step failed";
+        }
       }
     }
     d.done.fetch_add(1, std::memory_order_acq_rel);
@@ -1268,11 +1282,32 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   }
   int nl = cfg->predict_lanes > 0 ? cfg->predict_lanes : 2;
   if (nl > 16) nl = 16;
+  // Streams.  The runtime multiplexes every HIP stream of the process onto GPU_MAX_HW_QUEUES hardware queues (4 unless the
+  // environment says otherwise), a new stream taking the least-used queue, and the chip serves four compute queues at a
+  // time (tools/qmap.hip; profiles/README.md, "Hardware queues").  A prediction lane that lands on the train stream's
+  // queue waits behind whole train steps, and a fifth busy queue makes all of them take turns -- either way the train step
+  // is what slows down, and the engine's throughput is tied to it (every row served is trained once).  So the engine
+  // keeps to four streams that can be busy together: two for the prediction lanes, created first, then the train stream
+  // and its staging stream; lanes beyond two (Config.PREDICTORS > 2, the dynamic adjustment walking NP up) share those
+  // two streams in turn -- what the hardware queue would do to them anyway, without touching the train stream.
+  net->lane_streams = 2;
+  if (const char* e = getenv("GA3C_LANE_STREAMS")) net->lane_streams = atoi(e) > 0 ? atoi(e) : 2;
+  if (net->graphs) net->lane_streams = 16;     // a stream under capture cannot be shared
   for (int i = 0; i < nl; ++i) {
     Lane* L = new (std::nothrow) Lane();
     if (!L) { ga3c_net_destroy(net); return fail(GA3C_EINVAL, "out of host memory"); }
     net->lanes.push_back(L);
-    TRYHIP(hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking));
+    if (i < net->lane_streams) {
+      TRYHIP(hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking));
+    } else {
+      Lane* host = net->lanes[(size_t)(i % net->lane_streams)];
+      L->st = host->st;
+      L->owns_st = false;
+      L->shared_st = host->shared_st = true;
+    }
+    TRYHIP(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+    TRYHIP(hipEventCreate(&L->tm0));
+    TRYHIP(hipEventCreate(&L->tm1));
     TRY(alloc_fwd(L->f, maxB, A));
     TRYHIP(hipHostMalloc((void**)&L->h_in, (size_t)maxB * XS * sizeof(float), hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
@@ -1311,7 +1346,9 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (L->h_off) (void)hipHostFree(L->h_off);
     for (int k = 0; k < 2; ++k)
       if (L->read_done[k]) (void)hipEventDestroy(L->read_done[k]);
-    if (L->st) (void)hipStreamDestroy(L->st);
+    for (hipEvent_t e : {L->done, L->tm0, L->tm1})
+      if (e) (void)hipEventDestroy(e);
+    if (L->st && L->owns_st) (void)hipStreamDestroy(L->st);
     delete L;
   }
   free_train_lane(net->tr);
@@ -1717,17 +1754,14 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
     }
   }
   CHK(launch_frames(net, net->reg_dev, h_ag, h_reset, nullptr, n, h_src, L->st, h_slot));   // same stream as the forward pass
-  if (want == 0) {
-    HIPCHK(hipStreamSynchronize(L->st));
-    return GA3C_OK;
-  }
+  if (want == 0) return lane_wait(L);
   const int A = net->A;
   float* hp = L->h_out;
   float* hv = hp + (size_t)net->maxB * A;
   const int64_t t0 = now_ns();
   CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
   const int64_t t1 = now_ns();
-  HIPCHK(hipStreamSynchronize(L->st));
+  CHK(lane_wait(L));
   stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
   stat_add(net, GA3C_STAT_PREDICT_ROWS, want);
   stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
@@ -1792,7 +1826,7 @@ static int stage_history_rows(ga3c_net* net, Stage& s, const int32_t* agents, co
   for (int i = 0; i < batch; ++i) { h_seq[i] = seqs[i]; h_ag[i] = agents[i]; }
   const int64_t total = (int64_t)batch * (IMG * IMG / 4);
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 512) blocks = 512;      // (reads HBM, not the bus: two workgroups per CU leave the other wave slots to a step in flight)
   hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, s.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, s.xu8, batch);
   HIPCHK(hipGetLastError());
   s.x_u8 = true;   // (y_r and a are staged behind the x region of h_in: the ids at its start stay untouched)
@@ -1930,9 +1964,12 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
     Lane* L = net->lanes[0];
     PredictInFlight inflight(net);
     const auto h0 = std::chrono::steady_clock::now();
+    HIPCHK(hipEventRecord(L->tm0, L->st));
     for (int i = 0; i < iters; ++i) CHK(lane_step(net, *L, idx, batch, STEP_RESIDENT, nullptr, nullptr));
-    HIPCHK(hipStreamSynchronize(L->st));
+    HIPCHK(hipEventRecord(L->tm1, L->st));
+    HIPCHK(hipEventSynchronize(L->tm1));
     *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+    HIPCHK(hipEventElapsedTime(&net->lanes_gpu_ms, L->tm0, L->tm1));
     return GA3C_OK;
   }
   LaneDrivers& d = net->drv;
@@ -1959,6 +1996,21 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   for (int l = 0; l < nlanes; ++l)
     if (d.rcs[l] != GA3C_OK) return fail(d.rcs[l], "prediction lane %d failed: %s", l, d.errs[l].c_str());
+  // the block as the GPU saw it: from the earliest lane's start event to the latest lane's end event
+  float span = 0.f;
+  for (int i = 0; i < nlanes; ++i)
+    for (int j = 0; j < nlanes; ++j) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, net->lanes[i]->tm0, net->lanes[j]->tm1));
+      if (ms > span) span = ms;
+    }
+  net->lanes_gpu_ms = span;
+  return GA3C_OK;
+}
+
+int ga3c_net_last_lanes_gpu_ms(ga3c_net* net, float* gpu_ms) {
+  if (!net || !gpu_ms) return fail(GA3C_EINVAL, "null argument");
+  *gpu_ms = net->lanes_gpu_ms;
   return GA3C_OK;
 }
 

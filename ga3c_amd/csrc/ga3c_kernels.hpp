@@ -123,42 +123,45 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restric
 }
 
 // Gather of states straight out of the (HIP-registered) shared-memory transport: row b of the batch is the
-// 28,224 uint8 frames (or 28,224 f32) found at host_base + offsets[b]; written as f32 NHWC into x[b].
-// 16-byte reads over PCIe, one pass, conversion `k/128 - 1` fused.
-template <bool U8>
-__global__ __launch_bounds__(256) void gather_states_kernel(const uint8_t* __restrict__ host_base,
-                                                            const int64_t* __restrict__ offsets, float* __restrict__ x,
-                                                            int B) {
-  constexpr int CHUNKS = U8 ? XS / 16 : XS / 4;     // 16-byte chunks per state
-  const int64_t total = (int64_t)B * CHUNKS;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / CHUNKS), c = (int)(i - (int64_t)b * CHUNKS);
-    const uint8_t* src = host_base + offsets[b] + (size_t)c * 16;
-    if (U8) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(src);
-      const unsigned wds[4] = {raw.x, raw.y, raw.z, raw.w};
-      float* dst = x + (size_t)b * XS + (size_t)c * 16;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        f32x4 o = {(float)(wds[k] & 255u) * 0.0078125f - 1.0f, (float)((wds[k] >> 8) & 255u) * 0.0078125f - 1.0f,
-                   (float)((wds[k] >> 16) & 255u) * 0.0078125f - 1.0f, (float)(wds[k] >> 24) * 0.0078125f - 1.0f};
-        *reinterpret_cast<f32x4*>(dst + 4 * k) = o;
-      }
-    } else {
-      *reinterpret_cast<f32x4*>(x + (size_t)b * XS + (size_t)c * 4) = *reinterpret_cast<const f32x4*>(src);
-    }
-  }
+// Rows of a batch gathered out of the registered host segment (the shm transport), over PCIe, as they are: row b =
+// CHUNKS 16-byte chunks found at host_base + offsets[b] (28,224 uint8 frames: CHUNKS = 1764; 28,224 f32: 7056), written
+// densely to dst.  uint8 frames stay uint8: the conv kernels convert while staging.
+//
+// Work item = (row, piece of 256 chunks): the row's offset is uniform over the workgroup (one scalar load out of the
+// pinned offset array instead of a PCIe round trip per thread in front of every data load), four items are in flight per
+// thread, and the grid is NARROW (GATHER_MAX_BLOCKS workgroups of 4 waves).  The kernel waits on the bus, not on the chip:
+// launched as one chunk per thread it was 909 workgroups at 132 rows -- every wave slot of every CU held by waves waiting
+// for PCIe -- and the train step of the OTHER trainer thread, whose kernels are one 16-wave workgroup per CU, could not get
+// resident beside it: the staging of batch n+1 and step n ran one after the other although they sit on two streams.
+constexpr int GATHER_MAX_BLOCKS = 128;
+inline int gather_blocks(int B, int chunks) {
+  const int items = B * ((chunks + 255) / 256);
+  const int blocks = (items + 3) / 4;
+  return blocks < GATHER_MAX_BLOCKS ? (blocks < 1 ? 1 : blocks) : GATHER_MAX_BLOCKS;
 }
 
-// Same gather, uint8 frames kept as uint8 (28,224 B per state): the conv kernels convert while staging.
-__global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ host_base,
-                                                        const int64_t* __restrict__ offsets, uint8_t* __restrict__ xu8,
-                                                        int B) {
-  constexpr int CHUNKS = XS / 16;
-  const int64_t total = (int64_t)B * CHUNKS;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i / CHUNKS), c = (int)(i - (int64_t)b * CHUNKS);
-    reinterpret_cast<uint4*>(xu8)[i] = *reinterpret_cast<const uint4*>(host_base + offsets[b] + (size_t)c * 16);
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ host_base,
+                                                          const int64_t* __restrict__ offsets, uint4* __restrict__ dst, int B) {
+  constexpr int PIECES = (CHUNKS + 255) / 256;
+  const int items = B * PIECES;
+  const int tid = threadIdx.x;
+  for (int it0 = blockIdx.x * 4; it0 < items; it0 += gridDim.x * 4) {
+    uint4 v[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = it0 + u;
+      const int b = it / PIECES, c = (it - b * PIECES) * 256 + tid;
+      live[u] = it < items && c < CHUNKS;
+      if (live[u]) v[u] = *reinterpret_cast<const uint4*>(host_base + offsets[b] + (size_t)c * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = it0 + u;
+      const int b = it / PIECES, c = (it - b * PIECES) * 256 + tid;
+      if (live[u]) dst[(size_t)b * CHUNKS + c] = v[u];
+    }
   }
 }
 

@@ -118,6 +118,10 @@ int ga3c_net_time_resident(ga3c_net* net, int32_t mode, int32_t batch, int32_t i
 /* `iters` resident prediction steps dealt round-robin over `nlanes` prediction lanes (the NP predictor threads of
  * Config.PREDICTORS, each with its own HIP stream); host wall-clock from first launch to all lanes drained. */
 int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float* elapsed_ms);
+/* The block ga3c_net_time_predict_lanes timed last, as the GPU saw it: from the earliest lane's start event to the latest
+ * lane's end event (milliseconds).  Unlike the host clock it does not contain the launch latency of the first kernel and
+ * the wake-up of the waiting host threads, which at the driver's K = 20 are a tenth of a block. */
+int ga3c_net_last_lanes_gpu_ms(ga3c_net* net, float* gpu_ms);
 /* `iters` resident train steps dealt round-robin over `nlanes` train lanes of a net created with train_lanes >= 2
  * (nlanes = 1 works on any net); host wall-clock from the first launch to all lanes drained. */
 int ga3c_net_time_train_lanes(ga3c_net* net, int32_t batch, int32_t iters, int32_t nlanes, float learning_rate,

@@ -11,7 +11,7 @@ import json
 for k in ("k20","k300"):
     try:
         d=json.loads(open("gpurun_out/r03_a_bench_%s.json"%k).read().strip().splitlines()[-1])
-        print(k, "value %.3e ms/step %.5f inner %.5f"%(d["value"], d["ms_per_step"], d.get("ms_per_step_inner",0)), d["predict_lanes"], "train", d["train"]["ms_per_step"], d["train"].get("train_132"), d.get("predict_lanes_8_hw_queues"))
+        print(k, "value %.3e ms/step %.5f inner %.5f"%(d["value"], d["ms_per_step"], d.get("ms_per_step_wall",0)), d["predict_lanes"], "train", d["train"]["ms_per_step"], d["train"].get("train_132"), d.get("predict_lanes_8_hw_queues"))
     except Exception as e: print(k, "failed", e)
 PY
 timeout -k 10 200 python tools/train_latency.py 128 132 > gpurun_out/r03_a_train_latency.txt 2>&1; cat gpurun_out/r03_a_train_latency.txt | tail -8
