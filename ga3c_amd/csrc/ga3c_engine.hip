@@ -1028,7 +1028,18 @@ int train_body(ga3c_net* net, TrainLane& t, int B, float lr, float beta, float* 
 
 int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
   const int maxB = net->maxB, A = net->A;
-  HIPCHK(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
+  // The train stream is a high-priority stream: the runtime keeps a pool of hardware queues per priority, so it gets a
+  // queue that no prediction lane, no staging stream and not the null stream (which holds one of the four normal queues
+  // as soon as a hipMemcpy has run) can be multiplexed onto -- measured with tools/qmap.hip; the staging stream created
+  // as the fifth normal stream had landed on the train stream's queue and its gather ran behind the step it was meant to
+  // overlap (two trainer threads: 161 us per call, as slow as one).  Its kernels are also the ones that need every CU.
+  {
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const bool plain = getenv("GA3C_TRAIN_PRIORITY") && atoi(getenv("GA3C_TRAIN_PRIORITY")) == 0;
+    if (plain) HIPCHK(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
+    else HIPCHK(hipStreamCreateWithPriority(&t.st, hipStreamNonBlocking, hi));
+  }
   HIPCHK(hipStreamCreateWithFlags(&t.gst, hipStreamNonBlocking));
   CHK(alloc_fwd(t.f, maxB, A));
   for (int k = 0; k < 2; ++k) {

@@ -122,7 +122,6 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restric
   }
 }
 
-// Gather of states straight out of the (HIP-registered) shared-memory transport: row b of the batch is the
 // Rows of a batch gathered out of the registered host segment (the shm transport), over PCIe, as they are: row b =
 // CHUNKS 16-byte chunks found at host_base + offsets[b] (28,224 uint8 frames: CHUNKS = 1764; 28,224 f32: 7056), written
 // densely to dst.  uint8 frames stay uint8: the conv kernels convert while staging.

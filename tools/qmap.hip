@@ -29,6 +29,14 @@ int main(int argc, char** argv) {
   printf("GPU_MAX_HW_QUEUES=%s, %d normal streams + 1 high-priority stream (priority range %d..%d)\n",
          getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "default", S, lo, hi);
   std::vector<hipStream_t> st(S + 1);
+  if (argc > 2) {      // any second argument: use the null stream first, as a program that calls hipMemset / hipMemcpy does
+    int* p = nullptr;
+    CK(hipMalloc((void**)&p, 64));
+    CK(hipMemset(p, 0, 64));
+    hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, nullptr, nullptr);
+    CK(hipDeviceSynchronize());
+    printf("(the null stream has been used before the streams are created: pairs row/column N = the null stream)\n");
+  }
   for (int i = 0; i < S; ++i) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
   CK(hipStreamCreateWithPriority(&st[S], hipStreamNonBlocking, hi));
   for (auto s : st) { hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, s, nullptr); }
@@ -42,6 +50,19 @@ int main(int argc, char** argv) {
     for (int j = 0; j <= S; ++j) {
       if (i == j) { printf("  ."); continue; }
       hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[i], SPIN, nullptr);
+      const double t0 = now_us();
+      hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, st[j], nullptr);
+      CK(hipStreamSynchronize(st[j]));
+      const double dt = now_us() - t0;
+      CK(hipDeviceSynchronize());
+      printf("  %c", dt > 150.0 ? '#' : '-');
+    }
+    printf("\n");
+  }
+  if (argc > 2) {
+    printf("   N ");
+    for (int j = 0; j <= S; ++j) {
+      hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, nullptr, SPIN, nullptr);
       const double t0 = now_us();
       hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, st[j], nullptr);
       CK(hipStreamSynchronize(st[j]));
