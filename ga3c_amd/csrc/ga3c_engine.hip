@@ -262,6 +262,7 @@ struct ga3c_net {
   TensorTable tt;
   LaneDrivers drv;
   float lanes_gpu_ms = 0.f;            // GPU-side span of the last ga3c_net_time_predict_lanes block (first start event .. last end event)
+  int gather_max_blocks = 32;          // workgroups of the PCIe gather (GA3C_GATHER_BLOCKS; ga3c_kernels.hpp: gather_rows_kernel)
   int lane_streams = 2;                // HIP streams the prediction lanes are spread over (GA3C_LANE_STREAMS)
   // where the engine's calls spend their time (ga3c_net_stats): nanoseconds / counts, relaxed atomics
   std::atomic<int64_t> stat[GA3C_STAT_COUNT];
@@ -519,8 +520,9 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
       L.f.src_base = base;
       L.f.src_off = L.h_off;
     } else {
-      if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.xu8), B);
-      else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B);
+      const SmallCopy none{nullptr, nullptr, 0, nullptr, nullptr, 0};
+      if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.xu8), B, none);
+      else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B, none);
     }
   }
   const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
@@ -742,8 +744,7 @@ int stage_train_inputs(ga3c_net* net, TrainLane& t, const void* x, bool u8, cons
 }
 
 int read_losses(ga3c_net* net, TrainLane& t, float* losses) {
-  float* hl = t.h_out;
-  HIPCHK(hipMemcpyAsync(hl, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
+  const float* hl = t.losses;   // pinned host memory, written by the step itself
   HIPCHK(hipStreamSynchronize(t.st));
   if (!net->hogwild) {
     // the step this call enqueued has finished: predictions read its weights from now on (a caller that trains and
@@ -772,9 +773,8 @@ int evaluate_staged(ga3c_net* net, TrainLane& t, int B, float beta, float* losse
   hb.B = B; hb.A = net->A; hb.lossrow = t.lossrow; hb.losses = t.losses;
   hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, t.st, hb);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(t.h_out, t.losses, 3 * sizeof(float), hipMemcpyDeviceToHost, t.st));
   HIPCHK(hipStreamSynchronize(t.st));
-  if (losses) memcpy(losses, t.h_out, 3 * sizeof(float));
+  if (losses) memcpy(losses, t.losses, 3 * sizeof(float));
   if (d1) HIPCHK(hipMemcpy(d1, t.f.d1, (size_t)B * HID * sizeof(float), hipMemcpyDeviceToHost));
   if (v) HIPCHK(hipMemcpy(v, t.f.v, (size_t)B * sizeof(float), hipMemcpyDeviceToHost));
   if (p) HIPCHK(hipMemcpy(p, t.f.p, (size_t)B * net->A * sizeof(float), hipMemcpyDeviceToHost));
@@ -797,10 +797,25 @@ int stage_offsets(ga3c_net* net, const int64_t* offsets, int B, bool u8, int64_t
 
 // rows of a batch gathered from the registered host segment into x (device), on stream st; the gather kernel reads
 // the offsets out of the pinned host array itself: no H2D copy to wait for
-int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, Stage& s) {
+// y_r / a (either may be null) ride along: they are put into the pinned staging array and copied by the gather kernel itself
+int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, Stage& s, const float* y_r = nullptr, const float* a = nullptr) {
   CHK(stage_offsets(net, offsets, B, u8, s.h_off));
-  if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.xu8), B);
-  else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.x), B);
+  float* hy = s.h_in + (size_t)net->maxB * XS;
+  float* ha = hy + net->maxB;
+  SmallCopy sc{nullptr, nullptr, 0, nullptr, nullptr, 0};
+  if (y_r) {
+    memcpy(hy, y_r, (size_t)B * sizeof(float));
+    sc.src0 = hy; sc.dst0 = s.yr; sc.n0 = B;
+  }
+  if (a) {
+    memcpy(ha, a, (size_t)B * net->A * sizeof(float));
+    sc.src1 = ha; sc.dst1 = s.act; sc.n1 = B * net->A;
+  }
+  if (u8) {
+    hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.xu8), B, sc);
+  } else {
+    hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.x), B, sc);
+  }
   s.x_u8 = u8;
   HIPCHK(hipGetLastError());
   return GA3C_OK;
@@ -1003,7 +1018,15 @@ int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body) {
   in->x_u8 = s.x_u8;
   HIPCHK(hipEventRecord(in->ready, t->gst));
   const int64_t t1 = now_ns();
-  std::lock_guard<std::mutex> tl(t->mu);
+  // The lane goes from trainer thread to trainer thread while the steps follow each other on the GPU: a thread asleep in
+  // the mutex takes ~10 us to wake, during which the train stream is idle, so it spins for a step's length first
+  // (~23 us of waiting per call in the running engine).
+  {
+    bool got = false;
+    for (int spin = 0; spin < 4000 && !(got = t->mu.try_lock()); ++spin) __builtin_ia32_pause();
+    if (!got) t->mu.lock();
+  }
+  std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
   const int64_t t2 = now_ns();
   bind_intake(*t, *in);
   HIPCHK(hipStreamWaitEvent(t->st, in->ready, 0));
@@ -1066,7 +1089,10 @@ int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
   CHK(dmalloc(&t.dn1, (size_t)maxB * N1S));
   CHK(dmalloc(&t.slab2, (size_t)256 * SLAB2));   // conv2_dw: at most 256 sample groups
   CHK(dmalloc(&t.slab1, (size_t)512 * SLAB1));   // conv1_dw: at most 512 workgroups
-  CHK(dmalloc(&t.losses, 4));
+  // the three loss sums are written by the kernel that completes them straight into pinned host memory (as p and v of a
+  // prediction are): no copy kernel behind the step
+  HIPCHK(hipHostMalloc((void**)&t.losses, 4 * sizeof(float), hipHostMallocDefault));
+  memset(t.losses, 0, 4 * sizeof(float));
   CHK(dmalloc(&t.scales, 16));
   if (shared_grad) {
     t.grad = shared_grad;
@@ -1098,8 +1124,9 @@ void free_train_lane(TrainLane& t) {
   t.f.x = nullptr;
   t.f.xu8 = nullptr;
   free_fwd(t.f);
-  for (float* p : {t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.losses, t.scales})
+  for (float* p : {t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.scales})
     if (p) (void)hipFree(p);
+  if (t.losses) (void)hipHostFree(t.losses);
   if (t.owns_grad && t.grad) (void)hipFree(t.grad);
   if (t.h_out) (void)hipHostFree(t.h_out);
   if (t.gst) (void)hipStreamDestroy(t.gst);
@@ -1214,6 +1241,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1_HEADS")) net->d1_heads = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_GATHER_BLOCKS")) net->gather_max_blocks = atoi(e) > 0 ? atoi(e) : 32;
   for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CB_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) {
@@ -1496,10 +1524,7 @@ int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const 
   return with_staged_batch(
       net, batch,
       [&](Stage& s) {
-        if (offsets) {
-          CHK(launch_gather(net, offsets, batch, offsets_u8 != 0, s));
-          return stage_train_inputs(net, s, nullptr, false, y_r, a, batch);
-        }
+        if (offsets) return launch_gather(net, offsets, batch, offsets_u8 != 0, s, y_r, a);
         return stage_train_inputs(net, s, x ? (const void*)x : (const void*)x_u8, x == nullptr, y_r, a, batch);
       },
       [&](TrainLane& t) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); });
@@ -1552,10 +1577,7 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   if (!net || !offsets || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   return with_staged_batch(
       net, batch,
-      [&](Stage& s) {
-        CHK(launch_gather(net, offsets, batch, u8 != 0, s));
-        return stage_train_inputs(net, s, nullptr, false, y_r, a, batch);
-      },
+      [&](Stage& s) { return launch_gather(net, offsets, batch, u8 != 0, s, y_r, a); },
       [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
 }
 

@@ -128,23 +128,36 @@ __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restric
 //
 // Work item = (row, piece of 256 chunks): the row's offset is uniform over the workgroup (one scalar load out of the
 // pinned offset array instead of a PCIe round trip per thread in front of every data load), four items are in flight per
-// thread, and the grid is NARROW (GATHER_MAX_BLOCKS workgroups of 4 waves).  The kernel waits on the bus, not on the chip:
+// thread, and the grid is NARROW (ga3c_net::gather_max_blocks workgroups of 4 waves).  The kernel waits on the bus, not on the chip:
 // launched as one chunk per thread it was 909 workgroups at 132 rows -- every wave slot of every CU held by waves waiting
 // for PCIe -- and the train step of the OTHER trainer thread, whose kernels are one 16-wave workgroup per CU, could not get
 // resident beside it: the staging of batch n+1 and step n ran one after the other although they sit on two streams.
-constexpr int GATHER_MAX_BLOCKS = 128;
-inline int gather_blocks(int B, int chunks) {
+// Narrower still is better for the step it runs beside: the reads in flight also sit in the memory system's queues for
+// the length of a PCIe round trip, and the latency-bound kernels of the step (`heads`: 5 -> 37-63 us in the trace of
+// profiles/README.md) wait behind them; 32 workgroups x 4 x 4 KB in flight still saturate the bus (72 us for 3.6 MB),
+// 16 do not.  Two trainer threads, 128 rows, us per train call at 8 / 16 / 32 / 64 / 128 / 256 workgroups:
+// 200 / 129 / 116 / 123 / 134 / 143.
+inline int gather_blocks(int B, int chunks, int max_blocks) {
   const int items = B * ((chunks + 255) / 256);
   const int blocks = (items + 3) / 4;
-  return blocks < GATHER_MAX_BLOCKS ? (blocks < 1 ? 1 : blocks) : GATHER_MAX_BLOCKS;
+  return blocks < max_blocks ? (blocks < 1 ? 1 : blocks) : max_blocks;
 }
+
+// small arrays that ride along with a gather (a batch's returns and one-hot actions, out of the pinned staging array):
+// copied by the last workgroup, so that staging a batch is ONE launch instead of a gather and two copy kernels
+struct SmallCopy { const float* src0; float* dst0; int n0; const float* src1; float* dst1; int n1; };
 
 template <int CHUNKS>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ host_base,
-                                                          const int64_t* __restrict__ offsets, uint4* __restrict__ dst, int B) {
+                                                          const int64_t* __restrict__ offsets, uint4* __restrict__ dst, int B,
+                                                          SmallCopy sc) {
   constexpr int PIECES = (CHUNKS + 255) / 256;
   const int items = B * PIECES;
   const int tid = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int i = tid; i < sc.n0; i += 256) sc.dst0[i] = sc.src0[i];
+    for (int i = tid; i < sc.n1; i += 256) sc.dst1[i] = sc.src1[i];
+  }
   for (int it0 = blockIdx.x * 4; it0 < items; it0 += gridDim.x * 4) {
     uint4 v[4];
     bool live[4];

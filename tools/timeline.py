@@ -12,8 +12,14 @@ def short(n):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else len(rows) // 2
-    count = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+    if len(sys.argv) > 2 and not sys.argv[2].lstrip('-').isdigit():
+        # timeline.py trace.csv NAME N [count]: start at the N-th dispatch whose kernel name contains NAME
+        hits = [i for i, r in enumerate(rows) if sys.argv[2] in r['Kernel_Name']]
+        first = hits[int(sys.argv[3])] if len(sys.argv) > 3 else hits[len(hits) // 2]
+        count = int(sys.argv[4]) if len(sys.argv) > 4 else 40
+    else:
+        first = int(sys.argv[2]) if len(sys.argv) > 2 else len(rows) // 2
+        count = int(sys.argv[3]) if len(sys.argv) > 3 else 40
     t0 = int(rows[first]['Start_Timestamp'])
     busy_end = 0
     for r in rows[first:first + count]:

@@ -13,7 +13,7 @@ from NetworkVP import Network
 import _native as nat
 
 batches = [int(b) for b in sys.argv[1:]] or [32, 128, 130]
-t = tp.Transport.create(tp.unique_name("tlat"), 160, 6, 84 * 84 * 4, 8, 6)
+t = tp.Transport.create(tp.unique_name("tlat"), 160, 6, 84 * 84 * 4, 32, 6)
 net = Network("gpu:0", "tlat", 6, (84, 84, 4), max_batch=160, predict_lanes=2)
 net.register_transport(t)
 rng = np.random.default_rng(0)
@@ -21,6 +21,8 @@ t.agent_states[:] = rng.integers(0, 256, size=(160, 84 * 84 * 4), dtype=np.uint8
 net.learning_rate, net.beta = 3e-4, 0.01
 for n in batches:
     offs = t.state_offsets(np.arange(n, dtype=np.uint32))
+    if os.environ.get("TL_ROLLOUT_ROWS"):      # rows as they lie in rollout slots: runs of 6 contiguous rows
+        offs = np.concatenate([t.rollout_row_offsets(k, 6) for k in range((n + 5) // 6)])[:n]
     y = rng.uniform(-1, 1, n).astype(np.float32)
     a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, n)]
     for _ in range(30):
