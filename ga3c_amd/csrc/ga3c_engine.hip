@@ -428,7 +428,8 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     d.hb = hb;
     d.upd = upd;
     d.role_blocks = A + 2 < 14 ? A + 2 : 14;       // 242 tiles + the roles stay within one round of workgroups on 256 CUs
-    hipLaunchKernelGGL(dense1_bwd_tile_kernel, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+    if (upd.on) hipLaunchKernelGGL(dense1_bwd_tile_kernel<true>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+    else hipLaunchKernelGGL(dense1_bwd_tile_kernel<false>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
   } else {
     Dense1BwdArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
@@ -472,7 +473,8 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   {
     SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64, OFF_W1, OFF_B1};
     SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64, OFF_W2, OFF_B2};
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2, upd);
+    if (upd.on) hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2, upd);
+    else hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2, upd);
   }
   HIPCHK(hipGetLastError());
   if (overlap) {
@@ -1259,9 +1261,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
       return fail(GA3C_EHIP, "cannot reserve LDS for dense1_fwd_tile_kernel: %s", hipGetErrorString(e));
     }
   }
-  {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dense1_bwd_tile_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS * sizeof(float)));
+  for (const void* fn : {reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<true>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<false>)}) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) {
       delete net;
       return fail(GA3C_EHIP, "cannot reserve LDS for dense1_bwd_tile_kernel: %s", hipGetErrorString(e));
@@ -2160,7 +2161,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
       d.role_blocks = net->A + 2 < 14 ? net->A + 2 : 14;
       memset(&d.upd, 0, sizeof d.upd);
-      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
+      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<false>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, d);
     } else if (k == "heads") {
       HeadArgs h;
@@ -2181,7 +2182,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64, OFF_W2, OFF_B2};
       FusedUpd noupd;
       memset(&noupd, 0, sizeof noupd);
-      hipExtLaunchKernelGGL(slab_reduce_kernel, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2, noupd);
+      hipExtLaunchKernelGGL(slab_reduce_kernel<false>, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, t.st, t.ev0, t.ev1, 0, s1, s2, noupd);
     } else if (k == "rmsprop") {
       const int blocks = RMS_WD_BLOCKS + (int)((net->n - (int64_t)FLAT * HID + 255) / 256);
       TL((rmsprop_kernel<false, false>), dim3(blocks), th, net->theta[net->latest], net->ms, net->mom, t.grad, net->n,

@@ -544,17 +544,19 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
 // ------------------------------------------------------------------ conv12/w packed for conv2_dx
 // conv2_dx contracts dn2 with the 128 x 16 sub-matrix of W2 that belongs to an output-pixel parity class (py, px); its
 // B fragments, in the order the MFMAs consume them, are a permutation of W2's 8192 elements: element (u, v, c, o) of
-// W2[4,4,16,32] goes to class (1 - u%2, 1 - v%2), fragment j = s*4 + t with s = (u/2)*4 + (v/2)*2 + o/16, t = o%4,
-// lane = ((o%16)/4)*16 + c.  The packed copy lives behind dense1's packed copy (pk + FLAT*HID) and is kept current by
-// rmsprop_kernel / pack_w2dx_kernel, so a workgroup stages a class with ONE 16-byte load per thread.
+// W2[4,4,16,32] goes to class (1 - u%2, 1 - v%2), step s = (u/2)*4 + (v/2)*2 + o/16, MFMA t = o%4 of that step,
+// lane = ((o%16)/4)*16 + c, stored [class][s][lane][t]: the four B fragments a lane needs for the four MFMAs of a step are
+// ONE 16-byte LDS read (round 3; [class][s*4+t][lane] before: one 4-byte read per MFMA).  The packed copy lives behind
+// dense1's packed copy (pk + FLAT*HID) and is kept current by rmsprop_kernel / slab_reduce's fused update /
+// pack_w2dx_kernel, so a workgroup stages a class with ONE 16-byte load per thread.
 constexpr int64_t PK_W2DX = (int64_t)FLAT * HID;             // offset of the packed conv12/w inside the pk buffer
 constexpr int PK_FLOATS = FLAT * HID + 256 * 32;
 __host__ __device__ inline int w2dx_packed_index(int i) {   // i = index into W2[256][32] = ((u*4+v)*16 + c)*32 + o
   const int o = i & 31, k = i >> 5, c = k & 15, uv = k >> 4, u = uv >> 2, v = uv & 3;
   const int cls = (1 - (u & 1)) * 2 + (1 - (v & 1));
   const int s = ((u >> 1) << 2) | ((v >> 1) << 1) | (o >> 4);
-  const int j = s * 4 + (o & 3), ln = ((o & 15) >> 2) * 16 + c;
-  return cls * 2048 + j * 64 + ln;
+  const int t = o & 3, ln = ((o & 15) >> 2) * 16 + c;
+  return cls * 2048 + (s * 64 + ln) * 4 + t;
 }
 __global__ __launch_bounds__(256) void pack_w2dx_kernel(const float* __restrict__ w2, float* __restrict__ pk2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1265,12 +1267,11 @@ __device__ __forceinline__ void conv2_dx_tiles(const float* __restrict__ dnl, co
     for (int s = 0; s < 8; ++s)
       a[s] = ld4(dnl + ((ih - (s >> 2) + 1) * 12 + (jh - ((s >> 1) & 1) + 1)) * C2DX_CELL + (s & 1) * 16 + 4 * g);
     f32x4 acc0 = zero4(), acc1 = zero4();
-    float wq[2][8];                                      // the 8 weight fragments of an s pair, one pair ahead
-    auto load_w = [&](int s, float (&w8)[8]) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) w8[k] = wl[(s * 4 + k) * 64 + lane];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pin(w8[k]);
+    f32x4 wq[2][2];                                      // the weight fragments of an s pair (one 16-byte read per step), one pair ahead
+    auto load_w = [&](int s, f32x4 (&w2)[2]) {
+      w2[0] = ld4(wl + (s * 64 + lane) * 4);
+      w2[1] = ld4(wl + ((s + 1) * 64 + lane) * 4);
+      pin(w2[0]); pin(w2[1]);
     };
     load_w(0, wq[0]);
 #pragma unroll
@@ -1278,8 +1279,8 @@ __device__ __forceinline__ void conv2_dx_tiles(const float* __restrict__ dnl, co
       if (s + 2 < 8) load_w(s + 2, wq[((s >> 1) + 1) & 1]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc0 = mfma(a[s][t], wq[(s >> 1) & 1][t], acc0);
-        acc1 = mfma(a[s + 1][t], wq[(s >> 1) & 1][4 + t], acc1);
+        acc0 = mfma(a[s][t], wq[(s >> 1) & 1][0][t], acc0);
+        acc1 = mfma(a[s + 1][t], wq[(s >> 1) & 1][1][t], acc1);
       }
     }
 #pragma unroll
@@ -1353,6 +1354,7 @@ constexpr int D1B_LDS_FLOATS = D1B_ROWS * D1B_DS + D1B_COLS * D1B_DS + D1B_COLS 
 constexpr int D1B_TILES = FLAT / D1B_COLS;       // 242
 
 // head weight gradients / loss sums for a 1024-thread block (same arithmetic order as heads_bwd_role up to the fold width)
+template <bool UPD>
 __device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int role, float* lds, const FusedUpd& u) {
   f32x4* sacc = reinterpret_cast<f32x4*>(lds);            // [16][64]
   float* sh = lds + 16 * 64 * 4;                           // [16]
@@ -1397,12 +1399,12 @@ __device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int ro
       for (int q = 0; q < 4; ++q) {
         if (isv) h.g_wv[4 * kq + q] = tot[q];
         else h.g_wp[(size_t)(4 * kq + q) * h.A + o] = tot[q];
-        if (u.on) fused_rmsprop(u, isv ? OFF_WV + 4 * kq + q : OFF_WP + (int64_t)(4 * kq + q) * h.A + o, tot[q]);
+        if (UPD) fused_rmsprop(u, isv ? OFF_WV + 4 * kq + q : OFF_WP + (int64_t)(4 * kq + q) * h.A + o, tot[q]);
       }
     }
     if (k == 0) {
       if (isv) h.g_bv[0] = bsum; else h.g_bp[o] = bsum;
-      if (u.on) fused_rmsprop(u, isv ? OFF_BV : off_bp(h.A) + o, bsum);
+      if (UPD) fused_rmsprop(u, isv ? OFF_BV : off_bp(h.A) + o, bsum);
     }
   } else {
     for (int c = 0; c < 3; ++c) {
@@ -1420,10 +1422,14 @@ struct Dense1TileArgs {
   FusedUpd upd;      // on: dense1/w, dense1/b and the head parameters are stepped here (see FusedUpd)
 };
 
+// UPD: the launch also steps the parameters whose gradients it completes (FusedUpd; a.upd.on says the same at run time).
+// A template argument rather than a run-time switch so that the two forms are two kernels to a profiler: their HBM
+// traffic differs by the optimizer's 16 MB (profiles/: tools/pmc_table.py lists them as separate rows).
+template <bool UPD>
 __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float d1b_lds[];
   if ((int)blockIdx.x >= D1B_TILES) {                       // block-uniform: the head roles, dealt round-robin
-    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide(a.hb, role, d1b_lds, a.upd);
+    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide<UPD>(a.hb, role, d1b_lds, a.upd);
     return;
   }
   float* dds = d1b_lds;                                     // [128][260]  dd1 rows of the chunk
@@ -1434,6 +1440,15 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   const int B = a.B;
   f32x4 accw[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};   // dWd tiles n-tile 2 wv, 2 wv + 1 (waves 0-7), two chains each
   float bs0 = 0.f, bs1 = 0.f;
+  // fused update: the `ms` slot and the weights of the 16 x 256 tile this workgroup will step in its epilogue are requested
+  // NOW, with the staging loads, and arrive under the MFMAs -- fetched in the epilogue they were a memory round trip and a
+  // half in front of 4 MB of stores (13.4 us with the update against 8.6 us bare)
+  const int64_t uidx = (int64_t)(k0 + (threadIdx.x >> 6)) * HID + (threadIdx.x & 63) * 4;
+  f32x4 pre_ms = zero4(), pre_th = zero4();
+  if (UPD) {
+    pre_ms = ld4(a.upd.ms + OFF_WD + uidx);
+    pre_th = ld4(a.upd.tin + OFF_WD + uidx);
+  }
   for (int c0 = 0; c0 < B; c0 += D1B_ROWS) {
     const int rows = B - c0 < D1B_ROWS ? B - c0 : D1B_ROWS;      // real rows of this chunk
     const int prow = (rows + 15) & ~15;                          // padded to whole MFMA tiles
@@ -1544,7 +1559,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
       if (g == 0) {
         a.g_bd[n0 + r] = bs0;
         a.g_bd[n0 + 16 + r] = bs1;
-        if (a.upd.on) {
+        if (UPD) {
           fused_rmsprop(a.upd, OFF_BD + n0 + r, bs0);
           fused_rmsprop(a.upd, OFF_BD + n0 + 16 + r, bs1);
         }
@@ -1554,13 +1569,13 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   __syncthreads();
   {
     const int row = threadIdx.x >> 6, c4 = (threadIdx.x & 63) * 4;
-    const int64_t idx = (int64_t)(k0 + row) * HID + c4;
+    const int64_t idx = uidx;
     const f32x4 gv = ld4(gt + row * HID + c4);
     *reinterpret_cast<f32x4*>(a.g_wd + idx) = gv;
-    if (a.upd.on) {
+    if (UPD) {
       const FusedUpd& u = a.upd;
-      f32x4 m = ld4(u.ms + OFF_WD + idx);
-      const f32x4 th = ld4(u.tin + OFF_WD + idx);
+      f32x4 m = pre_ms;
+      const f32x4 th = pre_th;
       f32x4 mo = u.mu != 0.f ? ld4(u.mom + OFF_WD + idx) : zero4();
       f32x4 tn;
 #pragma unroll
@@ -1576,7 +1591,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
       *reinterpret_cast<f32x4*>(gt + row * HID + c4) = tn;       // for the fragment-ordered copy below
     }
   }
-  if (a.upd.on) {
+  if (UPD) {
     __syncthreads();
     // the fragment-ordered copy dense1_fwd reads: rows 4 kq .. 4 kq + 3 of column n are 16 contiguous bytes there
     const int n = threadIdx.x & 255, kq = threadIdx.x >> 8;
@@ -1791,9 +1806,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
     if (pr < 1 || pc < 1) *reinterpret_cast<f32x4*>(&dnimg[cell * C2DX_CELL + 4 * (i & 7)]) = zero4();
   }
   if (threadIdx.x < 256) ptab[threadIdx.x] = cb_class_pixel(h, threadIdx.x >> 7, (threadIdx.x >> 6) & 1, threadIdx.x & 63);
-  f32x4 acc2[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};          // [position of the pair][column half]
-  f32x4 acc1[4] = {zero4(), zero4(), zero4(), zero4()};                 // [m-tile of the group]
-  float bs2a = 0.f, bs2b = 0.f, bs1 = 0.f;
+  f32x4 acc2[4] = {zero4(), zero4(), zero4(), zero4()};                 // dW2: tile t, row r = row 64 u + 4 r + t
+  f32x4 acc1[4] = {zero4(), zero4(), zero4(), zero4()};                 // dW1: tile t, row r = row 64 mg + 4 r + t
+  float bs2 = 0.f, bs1 = 0.f;
   auto stage_x = [&](int b) {                                // the half's x rows of sample b -> xb (phase 3 reads them)
     const int y_base = 4 * r0 - 2;
     for (int idx = threadIdx.x; idx < CB_XROWS * C1_PW; idx += 1024) {
@@ -1849,15 +1864,12 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       f32x4 c0 = zero4(), c1 = zero4();
 #pragma unroll
       for (int s = 0; s < 8; s += 2) {
-        float wq[8];                                         // (4 waves per SIMD: the other waves cover this fetch)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wq[k] = wl[(s * 4 + k) * 64 + lane];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pin(wq[k]);
+        f32x4 w0 = ld4(wl + (s * 64 + lane) * 4), w1 = ld4(wl + ((s + 1) * 64 + lane) * 4);   // a step's four B fragments: one read
+        pin(w0); pin(w1);                                    // (4 waves per SIMD: the other waves cover this fetch)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          c0 = mfma(a[s][t], wq[t], c0);
-          c1 = mfma(a[s + 1][t], wq[4 + t], c1);
+          c0 = mfma(a[s][t], w0[t], c0);
+          c1 = mfma(a[s + 1][t], w1[t], c1);
         }
       }
       const int4 e4 = *reinterpret_cast<const int4*>(&tab[4 * g]);
@@ -1875,35 +1887,33 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
     }
     GA3C_STAMP(3);
     // ---- phase 2: dW2 partial over conv2 pixels q0 .. q0+c2npix-1 (slots to 64 carry dn2 = 0)
-    // wave = (positions 2*pp, 2*pp+1 -- same u, v and v+1 --, K half kh: steps 2*kh, 2*kh+1)
+    // wave = (patch row u, column half nh, K half kh: pixel slots 32 kh .. 32 kh + 31).  The 64 rows of dW2 that belong to
+    // patch row u -- positions (u, 0..3) x 16 channels -- are 64 CONTIGUOUS floats of the n1 image at every conv2 pixel, so
+    // a lane fetches ONE 16-byte piece (floats 4r .. 4r+3) and uses it as the A operand of four MFMAs: tile t, row r holds
+    // dW2 row 64 u + 4 r + t.  One wide LDS read per four MFMAs instead of four narrow ones; same sums in the same order.
     {
-      const int pp = wv & 7, kh = wv >> 3, u = pp >> 1, v0 = (pp & 1) * 2;
+      const int u = wv & 3, nh = (wv >> 2) & 1, kh = wv >> 3;
+      const float* abase = n1img + (u * C2_PW) * C1 + 4 * r;
 #pragma unroll 1
-      for (int ss = 0; ss < 2; ++ss) {
-        float a0[4], a1[4], b0[4], b1[4];
+      for (int s0 = 0; s0 < 8; s0 += 4) {
+        f32x4 a[4];
+        float bq[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int q = 16 * (2 * kh + ss) + 4 * t + g;
+        for (int s = 0; s < 4; ++s) {
+          const int q = 32 * kh + 4 * (s0 + s) + g;
           const bool ok = q < c2npix;
           const int qq = q0 + (ok ? q : 0);
           const int i2 = qq / O2, j2 = qq - i2 * O2;
-          const float* ap = n1img + ((2 * (i2 - c2r0) + u) * C2_PW + 2 * j2 + v0) * C1 + r;
-          a0[t] = ap[0];
-          a1[t] = ap[C1];
-          const float* bp = dnimg + (ok ? ((i2 + 1) * 12 + j2 + 1) * C2DX_CELL : 0);      // cell (0,0) is zero
-          b0[t] = bp[r];
-          b1[t] = bp[16 + r];
+          a[s] = ld4(abase + ((2 * (i2 - c2r0)) * C2_PW + 2 * j2) * C1);
+          bq[s] = dnimg[(ok ? ((i2 + 1) * 12 + j2 + 1) * C2DX_CELL : 0) + nh * 16 + r];       // cell (0,0) is zero
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { pin(a0[t]); pin(a1[t]); pin(b0[t]); pin(b1[t]); }
+        for (int s = 0; s < 4; ++s) { pin(a[s]); pin(bq[s]); }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          bs2a += b0[t];
-          bs2b += b1[t];
-          acc2[0][0] = mfma(a0[t], b0[t], acc2[0][0]);
-          acc2[0][1] = mfma(a0[t], b1[t], acc2[0][1]);
-          acc2[1][0] = mfma(a1[t], b0[t], acc2[1][0]);
-          acc2[1][1] = mfma(a1[t], b1[t], acc2[1][1]);
+        for (int s = 0; s < 4; ++s) {
+          bs2 += bq[s];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc2[t] = mfma(a[s][t], bq[s], acc2[t]);
         }
       }
     }
@@ -1911,13 +1921,18 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
     __syncthreads();                                         // dn1 of the half is complete in LDS; its x rows have landed
     GA3C_STAMP(5);
     // ---- phase 3: dW1 partial, band by band (no barrier between bands: the whole x image is resident);
-    // wave = (m-tiles 4*mg .. 4*mg+3, K quarter kq: pixel slots 16*kq .. 16*kq+15)
+    // wave = (row group mg: dW1 rows 64 mg .. 64 mg + 63 = patch rows 2 mg, 2 mg + 1, K quarter kq: pixel slots 16 kq ..
+    // 16 kq + 15 of the band).  As in phase 2 the 64 rows are two runs of 32 contiguous floats of the x image at every
+    // pixel (8 columns x 4 channels of one patch row), a lane fetches floats 4r .. 4r+3 of them as ONE 16-byte piece and
+    // feeds four MFMAs with it: tile t, row r = dW1 row 64 mg + 4 r + t.
     {
       const int mg = wv & 3, kq = wv >> 2;
-      float av[2][4][4], bv[2][4];
-      auto load_band = [&](int k, float (&a4)[4][4], float (&b4)[4]) {
+      const int aoff = (2 * mg + (r >> 3)) * (C1_PW * 4) + ((4 * r) & 31);
+      f32x4 av[2][4];
+      float bv[2][4];
+      auto load_band = [&](int k, f32x4 (&a4)[4], float (&b4)[4]) {
         const int brow0 = C1_HB * k;                         // first image row of the band
-        const float* img = xb + (4 * brow0) * (C1_PW * 4);
+        const float* img = xb + (4 * brow0) * (C1_PW * 4) + aoff;
         const int bpix = (NROWS - brow0 < C1_HB ? NROWS - brow0 : C1_HB) * O1;       // 63; 42 in the last band
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1926,21 +1941,12 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
           const int qc = ok ? q : 0;
           const int il = qc / O1, j = qc - il * O1;
           b4[t] = ok ? dn1l[(brow0 * O1 + q) * C1 + r] : 0.f;
-          const float* ap = img + (4 * il) * (C1_PW * 4) + 16 * j + r;
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int mt = mg * 4 + mi;                      // u = mt >> 1, v half = mt & 1
-            a4[t][mi] = ap[(mt >> 1) * (C1_PW * 4) + (mt & 1) * 16];
-          }
+          a4[t] = ld4(img + (4 * il) * (C1_PW * 4) + 16 * j);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          pin(b4[t]);
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) pin(a4[t][mi]);
-        }
+        for (int t = 0; t < 4; ++t) { pin(b4[t]); pin(a4[t]); }
       };
-      auto band_mfma = [&](const float (&a4)[4][4], const float (&b4)[4]) {
+      auto band_mfma = [&](const f32x4 (&a4)[4], const float (&b4)[4]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           bs1 += b4[t];
@@ -1965,38 +1971,38 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   {
     f32x4* red2 = reinterpret_cast<f32x4*>(cb_lds);          // everything staged above is dead now
     f32x4* red1 = red2 + 16 * 256;
-    float* redb = cb_lds + 2 * 16 * 1024;                    // bs2a, bs2b of waves 0 and 8; bs1 of waves 0, 4, 8, 12
+    float* redb = cb_lds + 2 * 16 * 1024;                    // bs2 of waves 0, 4, 8, 12 (u = 0: [kh][nh]); bs1 of waves 0, 4, 8, 12 (mg = 0: [kq])
     __syncthreads();
-    red2[wv * 256 + lane] = acc2[0][0]; red2[wv * 256 + 64 + lane] = acc2[0][1];
-    red2[wv * 256 + 128 + lane] = acc2[1][0]; red2[wv * 256 + 192 + lane] = acc2[1][1];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) red1[wv * 256 + 64 * mi + lane] = acc1[mi];
-    if ((wv & 7) == 0) { redb[(wv >> 3) * 128 + lane] = bs2a; redb[(wv >> 3) * 128 + 64 + lane] = bs2b; }
-    if ((wv & 3) == 0) redb[256 + (wv >> 2) * 64 + lane] = bs1;
+    for (int t = 0; t < 4; ++t) {
+      red2[wv * 256 + 64 * t + lane] = acc2[t];
+      red1[wv * 256 + 64 * t + lane] = acc1[t];
+    }
+    if ((wv & 3) == 0) {
+      redb[(wv >> 2) * 64 + lane] = bs2;                     // wave 4 nh + 8 kh -> slot nh + 2 kh
+      redb[256 + (wv >> 2) * 64 + lane] = bs1;
+    }
     __syncthreads();
     float* o2 = slab2 + (size_t)blockIdx.x * SLAB2;
     float* o1 = slab1 + (size_t)blockIdx.x * SLAB1;
-    if (wv < 8) {                                            // positions 2 wv, 2 wv + 1: K half 0 (wave wv) + K half 1 (wave wv + 8)
+    if (wv < 8) {                                            // (u, nh) = (wv & 3, wv >> 2): K half 0 (wave wv) + K half 1 (wave wv + 8)
+      const int u = wv & 3, nh = wv >> 2;
 #pragma unroll
-      for (int pi = 0; pi < 2; ++pi) {
-        const int mt = 2 * wv + pi;                          // patch position = m-tile of conv2_dw's slab layout
-        const f32x4 s0 = red2[wv * 256 + 128 * pi + lane] + red2[(wv + 8) * 256 + 128 * pi + lane];
-        const f32x4 s1 = red2[wv * 256 + 128 * pi + 64 + lane] + red2[(wv + 8) * 256 + 128 * pi + 64 + lane];
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 s0 = red2[wv * 256 + 64 * t + lane] + red2[(wv + 8) * 256 + 64 * t + lane];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          o2[(mt * 16 + 4 * g + q) * C2 + r] = s0[q];
-          o2[(mt * 16 + 4 * g + q) * C2 + 16 + r] = s1[q];
-        }
+        for (int q = 0; q < 4; ++q)                          // tile row 4 g + q = dW2 row 64 u + 4 (4 g + q) + t
+          o2[(64 * u + 4 * (4 * g + q) + t) * C2 + nh * 16 + r] = s0[q];
       }
-    } else if (wv < 12) {                                    // m-tiles 4 mg .. 4 mg + 3: K quarters = waves mg, mg + 4, mg + 8, mg + 12
+    } else if (wv < 12) {                                    // rows 64 mg ..: K quarters = waves mg, mg + 4, mg + 8, mg + 12
       const int mg = wv - 8;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        f32x4 tot = red1[mg * 256 + 64 * mi + lane];
+      for (int t = 0; t < 4; ++t) {
+        f32x4 tot = red1[mg * 256 + 64 * t + lane];
 #pragma unroll
-        for (int kq = 1; kq < 4; ++kq) tot += red1[(mg + 4 * kq) * 256 + 64 * mi + lane];
+        for (int kq = 1; kq < 4; ++kq) tot += red1[(mg + 4 * kq) * 256 + 64 * t + lane];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o1[((mg * 4 + mi) * 16 + 4 * g + q) * C1 + r] = tot[q];
+        for (int q = 0; q < 4; ++q) o1[(64 * mg + 4 * (4 * g + q) + t) * C1 + r] = tot[q];
       }
     } else if (wv == 12) {
       float ta = redb[lane] + redb[128 + lane], tb = redb[64 + lane] + redb[192 + lane];
@@ -2020,6 +2026,7 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
 // chunks w, w+16, ... (8 loads in flight), then wave 0 adds the 16 partial rows in order.
 struct SlabSet { const float* part; int nchunks; int stride; int nw; float* out_w; float* out_b; int nblocks; int64_t off_w; int64_t off_b; };
 
+template <bool UPD>
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s1, FusedUpd u) {
   __shared__ float sh[16][64];
   const bool first = (int)blockIdx.x < s0.nblocks;
@@ -2046,7 +2053,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s
 #pragma unroll
     for (int i = 0; i < 16; ++i) tot += sh[i][lane];
     if (e < ss.nw) ss.out_w[e] = tot; else ss.out_b[e - ss.nw] = tot;
-    if (u.on) {   // the conv parameters are stepped where their gradient is completed (off_w / off_b: arena offsets)
+    if (UPD) {    // the conv parameters are stepped where their gradient is completed (off_w / off_b: arena offsets)
       const int64_t i = e < ss.nw ? ss.off_w + e : ss.off_b + (e - ss.nw);
       const float tn = fused_rmsprop(u, i, tot);
       if (i >= OFF_W2 && i < OFF_B2) u.pk[PK_W2DX + w2dx_packed_index((int)(i - OFF_W2))] = tn;

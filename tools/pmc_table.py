@@ -28,6 +28,8 @@ def traffic_key(k):
         tag = ('_train' if args[0] == 'true' else '') + ('_u8' if args[1] == 'true' else '')
     elif base in ('conv1_dw', 'conv1_fwd', 'conv_bwd') and args:
         tag = '_u8' if args[0] == 'true' else ''
+    elif base in ('dense1_bwd_tile', 'slab_reduce') and args:
+        tag = '_upd' if args[0] == 'true' else ''
     elif base == 'heads' and args:
         tag = '_train' if args[0] == 'true' else ''
     elif args and base not in ('dense1_fwd', 'dense1_fwd_tile', 'rmsprop', 'frame_frontend', 'conv2_dx'):
@@ -45,12 +47,16 @@ ALGORITHMIC_MB = {
     "conv1_fwd_kernel<false>": X_F32 + N1, "conv2_fwd_kernel": N1 + N2,
     "dense1_fwd_tile_kernel<1>": N2 + WD + PART, "dense1_fwd_kernel<1>": N2 + WD + PART,
     "heads_kernel<false, 8>": PART + 0.14, "heads_kernel<true, 8>": PART + 0.28,
-    "dense1_bwd_tile_kernel": N2 + 0.13 + WD + WD + N2, "dense1_bwd_kernel": N2 + 0.13 + WD + WD + N2,
+    # <false>: gradients only; <true>: + the optimizer step of dense1/w in the epilogue (ms read + written, weights written,
+    # packed copy written: 4 x 3.96 MB; the weights themselves are read for the dn2 product either way)
+    "dense1_bwd_tile_kernel<false>": N2 + 0.13 + WD + WD + N2, "dense1_bwd_tile_kernel<true>": N2 + 0.13 + WD + WD + N2 + 4 * WD,
+    "dense1_bwd_kernel": N2 + 0.13 + WD + WD + N2,
     "dense1_dw_kernel": N2 + 0.13 + WD, "dense1_dx_kernel": 0.13 + WD + N2 + N2,
     "conv2_dw_kernel": N1 + N2 + 128 * 8224 * 4 / MB, "conv2_dx_kernel": N2 + N1 + N1,
     "conv1_dw_kernel<false>": X_F32 + N1 + 256 * 4112 * 4 / MB, "conv1_dw_kernel<true>": X_U8 + N1 + 256 * 4112 * 4 / MB,
     "conv_bwd_kernel<false>": X_F32 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB, "conv_bwd_kernel<true>": X_U8 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB,
-    "slab_reduce_kernel": (256 * 4112 + 128 * 8224) * 4 / MB, "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
+    "slab_reduce_kernel<false>": (256 * 4112 + 128 * 8224) * 4 / MB,
+    "slab_reduce_kernel<true>": (256 * 4112 + 128 * 8224) * 4 / MB + 5 * 12336 * 4 / MB,       # + RMSProp over the 12,336 conv parameters "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
     "pack_wd_kernel": 2 * WD, "frame_frontend_kernel<3>": 256 * 157248 / MB,
 }
 
