@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <atomic>
 #include <sched.h>
@@ -65,6 +66,15 @@ int fail(int code, const char* fmt, ...) {
     int _r = (expr);           \
     if (_r != GA3C_OK) return _r; \
   } while (0)
+
+// rocTX ranges around the engine's calls (tracing): `rocprofv3 --marker-trace` shows ga3c.predict /
+// ga3c.train.stage / ga3c.train.step on the host timeline beside the kernels; a no-op without a profiler attached
+struct TraceRange {
+  explicit TraceRange(const char* name) { roctxRangePushA(name); }
+  ~TraceRange() { roctxRangePop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
 
 inline int64_t now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -922,6 +932,7 @@ int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, 
   float* hv = hp + (size_t)net->maxB * A;
   float* hz = hv + net->maxB;
   // the heads kernel stores p and v straight into the lane's pinned host buffer: no D2H copies on the round trip
+  TraceRange range("ga3c.predict");
   const int64_t t0 = now_ns();
   CHK(lane_forward(net, *L, B, mode, hp, hv));
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
@@ -1013,12 +1024,15 @@ int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body) {
   HIPCHK(hipSetDevice(net->cfg.device));
   TrainLane* t = pick_train_lane(net);
   const int64_t t0 = now_ns();
+  roctxRangePushA("ga3c.train.stage");
+  struct PopOnce { bool live = true; void pop() { if (live) { roctxRangePop(); live = false; } } ~PopOnce() { pop(); } } stage_range;
   Intake* in = take_intake(*t);
   std::lock_guard<std::mutex> ig(in->mu, std::adopt_lock);
   Stage s = intake_stage(*t, *in);
   CHK(stage(s));
   in->x_u8 = s.x_u8;
   HIPCHK(hipEventRecord(in->ready, t->gst));
+  stage_range.pop();
   const int64_t t1 = now_ns();
   // The lane goes from trainer thread to trainer thread while the steps follow each other on the GPU: a thread asleep in
   // the mutex takes ~10 us to wake, during which the train stream is idle, so it spins for a step's length first
@@ -1039,6 +1053,7 @@ int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body) {
 
 // the body of every train entry point: forward, backward, update, then wait for the step and hand back its losses
 int train_body(ga3c_net* net, TrainLane& t, int B, float lr, float beta, float* losses) {
+  TraceRange range("ga3c.train.step");
   const int64_t t0 = now_ns();
   CHK(train_grads(net, t, B, beta, true, lr));
   CHK(train_apply(net, t, lr));
@@ -1792,6 +1807,7 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   const int A = net->A;
   float* hp = L->h_out;
   float* hv = hp + (size_t)net->maxB * A;
+  TraceRange range("ga3c.predict_frames");
   const int64_t t0 = now_ns();
   CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
   const int64_t t1 = now_ns();

@@ -206,3 +206,106 @@ def test_golden_fixture_losses_gradients_and_update_norms(nets, golden_dir):
         finally:
             if num_actions == 4:
                 net.close()
+
+
+def test_two_trainer_threads_pipeline_and_stay_reproducible():
+    """Config.TRAINERS = 2 (Server.py:132-134): two threads call train_offsets concurrently.  Each thread stages its rows into an
+    intake of its own on the staging stream while the other thread's step is in flight; the steps themselves are taken one
+    after the other (the lane's mutex), so with both threads training the SAME rows the result must equal the same number of
+    sequential steps from one thread bit for bit -- whatever the interleaving was -- and the engine's counters must show
+    both calls and rows."""
+    import threading
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    import Transport as tp
+    bsz, per_thread = 132, 6
+    t = tp.Transport.create(tp.unique_name("t_pipe"), 4, 6, 84 * 84 * 4, 24, 6)
+    net = Network("gpu:0", "pipe", 6, (84, 84, 4), max_batch=136, predict_lanes=1)
+    try:
+        net.register_transport(t)
+        xk, _, a, y = _batch(bsz, 6, 999)
+        rows = xk.reshape(bsz, -1)
+        offs = []
+        for k in range(22):
+            states, _, _ = t.rollout_views(k)
+            states[:6] = rows[6 * k:6 * k + 6]
+            offs.append(t.rollout_row_offsets(k, 6))
+        offs = np.concatenate(offs)
+        _reset(net, 6)
+        for _ in range(2 * per_thread):
+            net.train_offsets(offs, y, a)
+        want_w, want_ms = net.get_arena(0), net.get_arena(1)
+        _reset(net, 6)
+        net.stats(reset=True)
+        errors = []
+
+        def trainer():
+            try:
+                for _ in range(per_thread):
+                    net.train_offsets(offs, y, a)
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+        ths = [threading.Thread(target=trainer) for _ in range(2)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(60)
+        assert not errors, errors
+        assert np.array_equal(net.get_arena(0), want_w) and np.array_equal(net.get_arena(1), want_ms)
+        st = net.stats()
+        assert st["train_calls"] == 2 * per_thread and st["train_rows"] == 2 * per_thread * bsz
+        assert st["train_sync_ns"] > 0 and st["train_launch_ns"] > 0 and st["train_stage_ns"] > 0
+    finally:
+        net.close()
+        t.shutdown()
+        t.close()
+
+
+def test_four_prediction_lanes_on_two_streams_agree_with_one_lane():
+    """Lanes beyond two share the two prediction streams (ga3c_net_create: the engine keeps to four busy streams).  Four
+    threads predict concurrently through four lanes; every answer must equal the single-lane answer bit for bit, and a lane
+    must never return before ITS step is done although another lane's later work sits on the same stream."""
+    import threading
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    one = Network("gpu:0", "one", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
+    four = Network("gpu:0", "four", 6, (84, 84, 4), max_batch=64, predict_lanes=4)
+    try:
+        batches = [_batch(7 + 9 * k, 6, 50 + k)[0] for k in range(4)]
+        want = [one.predict_p_and_v(b) for b in batches]
+        errors = []
+
+        def worker(k):
+            try:
+                for _ in range(40):
+                    p, v = four.predict_p_and_v(batches[k])
+                    if not (np.array_equal(p, want[k][0]) and np.array_equal(v, want[k][1])):
+                        errors.append("lane thread %d: answer differs from the single-lane answer" % k)
+                        return
+            except Exception as e:   # noqa: BLE001
+                errors.append(repr(e))
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join(60)
+        assert not errors, errors
+        st = four.stats()
+        assert st["predict_calls"] == 160 and st["predict_rows"] == 40 * sum(b.shape[0] for b in batches)
+    finally:
+        one.close()
+        four.close()
+
+
+def test_comm_info_reports_what_the_communicator_says():
+    """bench.py's rccl_ranks comes from ncclCommCount / ncclCommUserRank of the attached communicator (ga3c_net_comm_info),
+    not from the launcher's environment: (0, -1, -1) without one, (1, 0, device) for a one-rank communicator."""
+    import ga3c_amd  # noqa: F401
+    from NetworkVP import Network
+    net = Network("gpu:0", "ci", 6, (84, 84, 4), max_batch=8, predict_lanes=1)
+    try:
+        assert net.comm_info() == (0, -1, -1)
+        net.comm_init(Network.make_comm_id(), 0, 1)
+        assert net.comm_info() == (1, 0, 0)
+    finally:
+        net.close()
