@@ -28,6 +28,8 @@ def traffic_key(k):
         tag = ('_train' if args[0] == 'true' else '') + ('_u8' if args[1] == 'true' else '')
     elif base in ('conv1_dw', 'conv1_fwd', 'conv_bwd') and args:
         tag = '_u8' if args[0] == 'true' else ''
+    elif base in ('dense1_fwd_tile', 'dense1_fwd') and args:
+        tag = '' if args[0] == '1' else '_mt' + args[0]
     elif base in ('dense1_bwd_tile', 'slab_reduce') and args:
         tag = '_upd' if args[0] == 'true' else ''
     elif base == 'heads' and args:
@@ -55,8 +57,10 @@ ALGORITHMIC_MB = {
     "conv2_dw_kernel": N1 + N2 + 128 * 8224 * 4 / MB, "conv2_dx_kernel": N2 + N1 + N1,
     "conv1_dw_kernel<false>": X_F32 + N1 + 256 * 4112 * 4 / MB, "conv1_dw_kernel<true>": X_U8 + N1 + 256 * 4112 * 4 / MB,
     "conv_bwd_kernel<false>": X_F32 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB, "conv_bwd_kernel<true>": X_U8 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB,
-    "slab_reduce_kernel<false>": (256 * 4112 + 128 * 8224) * 4 / MB,
-    "slab_reduce_kernel<true>": (256 * 4112 + 128 * 8224) * 4 / MB + 5 * 12336 * 4 / MB,       # + RMSProp over the 12,336 conv parameters "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
+    # slabs read once: train steps reduce the 256 slab pairs of conv_bwd (256 x (4112 + 8224) floats), the per-kernel timer
+    # the 512 + 128 slabs of the split kernels -- 12.63 MB either way
+    "slab_reduce_kernel<false>": 256 * (4112 + 8224) * 4 / MB,
+    "slab_reduce_kernel<true>": 256 * (4112 + 8224) * 4 / MB + 5 * 12336 * 4 / MB,       # + RMSProp over the 12,336 conv parameters "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
     "pack_wd_kernel": 2 * WD, "frame_frontend_kernel<3>": 256 * 157248 / MB,
 }
 
