@@ -102,8 +102,8 @@ struct Lane {
   float* h_in = nullptr;    // pinned staging, max_batch states
   float* h_out = nullptr;   // pinned staging, p|v|z
   int64_t* h_off = nullptr; // pinned: per-row byte offsets, read in place by the gather kernels
-  hipEvent_t read_done[2] = {nullptr, nullptr};
-  bool dirty[2] = {false, false};   // read_done[i] recorded since theta[i] was last written (guarded by wmu)
+  hipEvent_t read_done[3] = {nullptr, nullptr, nullptr};
+  bool dirty[3] = {false, false, false};   // read_done[i] recorded since theta[i] was last written (guarded by wmu)
   // captured prediction steps, one executable graph per (batch, weight buffer, intake mode, output target): every
   // pointer a step touches is fixed for the lane's lifetime, so a step is replayed with ONE launch call
   std::unordered_map<int64_t, hipGraphExec_t> graphs;
@@ -124,6 +124,9 @@ struct Intake {
   float* h_in = nullptr;    // pinned: x | y_r | a
   int64_t* h_off = nullptr; // pinned: per-row byte offsets / plane sequence numbers, read in place by the gather kernels
   hipEvent_t ready = nullptr;   // recorded on the staging stream behind the batch
+  hipEvent_t done = nullptr;    // recorded on the train stream behind the step that trained this batch
+  float* losses = nullptr;      // pinned: the three loss sums of that step, written by the kernel that completes them
+  int wbuf = -1;                // the weight buffer that step wrote (-1: none, or updated in place)
   bool x_u8 = false;
 };
 
@@ -152,6 +155,7 @@ struct TrainLane {
   bool exchanged = false;   // the gradients in `grad` have been all-reduced by the backward pass itself (overlapped exchange)
   bool stepped = false;     // the backward pass has applied RMSProp itself (FusedUpd) into theta[stepped_other]
   int stepped_other = 0;
+  int wrote = -1;           // the weight buffer the step enqueued last on this lane wrote (publish_other_buffer)
 };
 
 // K slices of dense1_fwd.  Its grid is (row blocks) x (2 column halves) x (slices), every slice a partial slab that
@@ -217,20 +221,26 @@ struct ga3c_net {
   int A = 0;
   int maxB = 0;
   int64_t n = 0;   // arena floats
-  float* theta[2] = {nullptr, nullptr};
-  float* theta_pk[2] = {nullptr, nullptr};   // dense1/w of theta[i] in dense1_fwd's fragment order
-  // Double-buffered weights.  `latest` is the buffer the newest optimizer step wrote (train-stream order; everything on
-  // the train side reads it); `cur` is the buffer prediction lanes read: it follows `latest` only once that step has
-  // FINISHED on the GPU, so a prediction never queues behind a train step in flight (it reads weights one step old
-  // instead -- the reference's predictors read weights in the middle of an update).
+  static constexpr int NBUF = 3;
+  float* theta[NBUF] = {nullptr, nullptr, nullptr};
+  float* theta_pk[NBUF] = {nullptr, nullptr, nullptr};   // dense1/w of theta[i] in dense1_fwd's fragment order (+ the packed conv12/w)
+  // Triple-buffered weights (round 3; two buffers before).  `latest` is the buffer the newest ENQUEUED optimizer step wrote
+  // (train-stream order; everything on the train side reads it); `cur` is the buffer prediction lanes read: it only ever
+  // advances to a buffer whose step has FINISHED on the GPU, so a prediction never queues behind a train step in flight (it
+  // reads weights one or two steps old instead -- the reference's predictors read weights in the middle of an update).
+  // A step reads theta[latest] and writes a buffer that is neither `latest` nor `cur`: with three buffers there always is
+  // one, also while the previous step is still in flight -- which is what lets two trainer threads enqueue their steps back
+  // to back (with two buffers the second step had to move the predictions onto weights still being written, and every
+  // prediction issued meanwhile waited for that step).
   std::atomic<int> cur{0};
   int latest = 0;
-  bool must_wait[2] = {false, false};   // cur was advanced before theta_ready[cur] completed (steps enqueued back to back)
-  bool event_valid[2] = {false, false}; // theta_ready[i] was recorded behind the step that wrote theta[i]
+  uint64_t wseq[NBUF] = {0, 0, 0};      // number of the step that wrote theta[i] (guarded by wmu): newer = larger
+  uint64_t wcount = 0;
+  bool event_valid[NBUF] = {false, false, false};   // theta_ready[i] was recorded behind the step that wrote theta[i]
   std::atomic<uint64_t> pred_seq{0};    // prediction steps launched so far; the optimizer records theta_ready only while
   uint64_t pred_seen = 0;               // predictions are arriving (an event per step costs a train-only loop ~3 us)
   float *grad = nullptr, *ms = nullptr, *mom = nullptr;
-  hipEvent_t theta_ready[2] = {nullptr, nullptr};   // recorded on the train stream behind the step that wrote theta[i]
+  hipEvent_t theta_ready[NBUF] = {nullptr, nullptr, nullptr};   // recorded on the train stream behind the step that wrote theta[i]
   std::mutex ready_mu;
   std::shared_mutex wmu;   // shared: a forward pass picking/reading theta[cur]; unique: the optimizer flip
   std::vector<Lane*> lanes;
@@ -575,62 +585,48 @@ int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, fl
   return GA3C_OK;
 }
 
+// cur <- the newest buffer whose step has finished (ready_mu held; wmu held shared or unique).  An event the optimizer did
+// not record (no predictions were around) is recorded now, at the tail of the train stream: it then completes no earlier
+// than the step it stands for.
+int adopt_finished(ga3c_net* net) {
+  const int c = net->cur.load(), l = net->latest;
+  if (l == c) return GA3C_OK;
+  const int m = 3 - l - c;                                   // the buffer enqueued between them, if any
+  for (int cand : {l, m}) {
+    if (net->wseq[cand] <= net->wseq[c]) continue;
+    if (!net->event_valid[cand]) {
+      HIPCHK(hipEventRecord(net->theta_ready[cand], net->tr.st));
+      net->event_valid[cand] = true;
+    }
+    if (hipEventQuery(net->theta_ready[cand]) == hipSuccess) {
+      net->cur.store(cand);
+      return GA3C_OK;
+    }
+  }
+  return GA3C_OK;
+}
+
 int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* out_v) {
   std::shared_lock<std::shared_mutex> lk(net->wmu);
   net->pred_seq.fetch_add(1);
-  int idx = net->cur.load();
-  if (net->latest != idx) {
+  if (net->latest != net->cur.load()) {
     std::lock_guard<std::mutex> g(net->ready_mu);
-    const int nw = net->latest;
-    if (!net->event_valid[nw]) {
-      // the optimizer saw no predictions around and skipped the event: mark the tail of the train stream now
-      HIPCHK(hipEventRecord(net->theta_ready[nw], net->tr.st));
-      net->event_valid[nw] = true;
-    }
-    if (net->cur.load() != nw && hipEventQuery(net->theta_ready[nw]) == hipSuccess) {
-      // the optimizer step that wrote the other buffer has finished: predictions move over to it
-      net->must_wait[nw] = false;
-      net->cur.store(nw);
-    }
-    idx = net->cur.load();
+    CHK(adopt_finished(net));
   }
-  bool wait;
-  {
-    std::lock_guard<std::mutex> g(net->ready_mu);
-    wait = net->must_wait[idx];
-    if (wait) {
-      if (!net->event_valid[idx]) {   // nobody has marked the step that wrote this buffer yet
-        HIPCHK(hipEventRecord(net->theta_ready[idx], net->tr.st));
-        net->event_valid[idx] = true;
-      }
-      if (hipEventQuery(net->theta_ready[idx]) == hipSuccess) wait = net->must_wait[idx] = false;
-    }
-  }
-  if (wait) {
-    HIPCHK(hipStreamWaitEvent(L.st, net->theta_ready[idx], 0));
-    stat_add(net, GA3C_STAT_PREDICT_WEIGHT_WAITS, 1);
-  }
+  const int idx = net->cur.load();      // a finished step's weights: nothing to wait for
   CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
   return GA3C_OK;
 }
 
-// gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller)
-// Before the weight buffer `other` = 1 - latest is overwritten: predictions move over to `latest` (they may have to wait for
-// the step that wrote it), and the train stream waits for every prediction lane that has read `other` since it was last
-// written.  Cross-stream events cost several microseconds of queue idle each on this stack, so they are used only when a
-// lane has really touched the buffer.
+// The buffer the next optimizer step writes: neither `latest` (the step reads it) nor `cur` (predictions read it).  The
+// train stream waits for every prediction lane that has read that buffer since it was last written.  Cross-stream events
+// cost several microseconds of queue idle each on this stack, so they are used only when a lane has really touched it.
 int claim_other_buffer(ga3c_net* net, TrainLane& t, int* idx_out, int* other_out) {
   std::unique_lock<std::shared_mutex> lk(net->wmu);
-  const int idx = net->latest, other = 1 - idx;
-  if (net->cur.load() != idx) {
-    // no prediction has moved over to the previous step's weights yet, and this step is about to overwrite the buffer
-    // predictions still read: move them now; they wait for that step only if it is still in flight
-    // (without an event -- no predictions were around -- the next prediction marks the train stream itself and waits)
-    net->must_wait[idx] = net->event_valid[idx] ? hipEventQuery(net->theta_ready[idx]) != hipSuccess : true;
-    net->cur.store(idx);
-  }
+  const int idx = net->latest, c = net->cur.load();
+  const int other = c == idx ? (idx + 1) % 3 : 3 - idx - c;
   for (Lane* L : net->lanes) {
     if (L->dirty[other]) {
       HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
@@ -651,8 +647,18 @@ int publish_other_buffer(ga3c_net* net, TrainLane& t, int other) {
   net->pred_seen = seq;
   if (net->event_valid[other]) HIPCHK(hipEventRecord(net->theta_ready[other], t.st));
   net->latest = other;
+  net->wseq[other] = ++net->wcount;
   net->step.fetch_add(1);
+  t.wrote = other;
   return GA3C_OK;
+}
+
+// the step that wrote theta[buf] is known to have finished (its caller has waited for it): predictions may read it
+void adopt_buffer(ga3c_net* net, int buf) {
+  if (buf < 0) return;
+  std::shared_lock<std::shared_mutex> lk(net->wmu);
+  std::lock_guard<std::mutex> g(net->ready_mu);
+  if (net->wseq[buf] > net->wseq[net->cur.load()]) net->cur.store(buf);
 }
 
 // gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller).  will_apply: the
@@ -719,6 +725,7 @@ Stage intake_stage(TrainLane& t, Intake& in) { return Stage{in.x, in.xu8, in.yr,
 void bind_intake(TrainLane& t, Intake& in) {
   t.f.x = in.x; t.f.xu8 = in.xu8; t.f.x_u8 = in.x_u8;
   t.yr = in.yr; t.act = in.act; t.h_in = in.h_in; t.h_off = in.h_off;
+  t.losses = in.losses;
 }
 
 int stage_train_inputs(ga3c_net* net, Stage& s, const void* x, bool u8, const float* y_r, const float* a, int B) {
@@ -759,11 +766,10 @@ int read_losses(ga3c_net* net, TrainLane& t, float* losses) {
   const float* hl = t.losses;   // pinned host memory, written by the step itself
   HIPCHK(hipStreamSynchronize(t.st));
   if (!net->hogwild) {
-    // the step this call enqueued has finished: predictions read its weights from now on (a caller that trains and
-    // then predicts sees the new weights; in the engine the trainer thread moves the predictors over right here)
+    // everything this lane enqueued has finished: predictions read the newest weights from now on (a caller that trains
+    // and then predicts sees the new weights)
     std::shared_lock<std::shared_mutex> lk(net->wmu);
     std::lock_guard<std::mutex> g(net->ready_mu);
-    net->must_wait[net->latest] = false;
     net->cur.store(net->latest);
   }
   if (losses) memcpy(losses, hl, 3 * sizeof(float));
@@ -1018,8 +1024,8 @@ struct ResidentHold {
 // calling thread owns that intake for the whole call); then, in the lane's turn, `body` runs with the intake bound to the
 // lane and the train stream ordered behind the staging.  While one thread is inside `body` (a step in flight), the next
 // thread's `stage` -- the PCIe gather of its rows -- proceeds on the staging stream.
-template <class StageFn, class BodyFn>
-int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body) {
+template <class StageFn, class BodyFn, class DoneFn>
+int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body, DoneFn&& done) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
   TrainLane* t = pick_train_lane(net);
@@ -1034,36 +1040,47 @@ int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body) {
   HIPCHK(hipEventRecord(in->ready, t->gst));
   stage_range.pop();
   const int64_t t1 = now_ns();
-  // The lane goes from trainer thread to trainer thread while the steps follow each other on the GPU: a thread asleep in
-  // the mutex takes ~10 us to wake, during which the train stream is idle, so it spins for a step's length first
-  // (~23 us of waiting per call in the running engine).
   {
+    // The lane goes from trainer thread to trainer thread while the steps follow each other on the GPU: a thread asleep in
+    // the mutex takes ~10 us to wake, so it spins for a step's length first (~23 us of waiting per call in the running engine).
     bool got = false;
     for (int spin = 0; spin < 4000 && !(got = t->mu.try_lock()); ++spin) __builtin_ia32_pause();
     if (!got) t->mu.lock();
+    std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
+    const int64_t t2 = now_ns();
+    bind_intake(*t, *in);
+    HIPCHK(hipStreamWaitEvent(t->st, in->ready, 0));
+    stat_add(net, GA3C_STAT_TRAIN_STAGE_NS, t1 - t0);
+    stat_add(net, GA3C_STAT_TRAIN_LANE_WAIT_NS, t2 - t1);
+    CHK(body(*t, *in));
   }
-  std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
-  const int64_t t2 = now_ns();
-  bind_intake(*t, *in);
-  HIPCHK(hipStreamWaitEvent(t->st, in->ready, 0));
-  stat_add(net, GA3C_STAT_TRAIN_STAGE_NS, t1 - t0);
-  stat_add(net, GA3C_STAT_TRAIN_LANE_WAIT_NS, t2 - t1);
-  return body(*t);
+  // the lane is free again: the next thread enqueues ITS step right behind this one while this thread waits for its own
+  return done(*t, *in);
 }
 
-// the body of every train entry point: forward, backward, update, then wait for the step and hand back its losses
-int train_body(ga3c_net* net, TrainLane& t, int B, float lr, float beta, float* losses) {
+// the body of every train entry point, under the lane's mutex: forward, backward, update ENQUEUED, an event behind them
+int train_enqueue(ga3c_net* net, TrainLane& t, Intake& in, int B, float lr, float beta) {
   TraceRange range("ga3c.train.step");
   const int64_t t0 = now_ns();
+  t.wrote = -1;
   CHK(train_grads(net, t, B, beta, true, lr));
   CHK(train_apply(net, t, lr));
-  const int64_t t1 = now_ns();
-  const int rc = read_losses(net, t, losses);
+  in.wbuf = net->hogwild ? -1 : t.wrote;
+  HIPCHK(hipEventRecord(in.done, t.st));
   stat_add(net, GA3C_STAT_TRAIN_CALLS, 1);
   stat_add(net, GA3C_STAT_TRAIN_ROWS, B);
-  stat_add(net, GA3C_STAT_TRAIN_LAUNCH_NS, t1 - t0);
-  stat_add(net, GA3C_STAT_TRAIN_SYNC_NS, now_ns() - t1);
-  return rc;
+  stat_add(net, GA3C_STAT_TRAIN_LAUNCH_NS, now_ns() - t0);
+  return GA3C_OK;
+}
+
+// ... and, with the lane released: wait for THIS step, hand its weights to the predictions, return its losses
+int train_finish(ga3c_net* net, Intake& in, float* losses) {
+  const int64_t t0 = now_ns();
+  HIPCHK(hipEventSynchronize(in.done));
+  adopt_buffer(net, in.wbuf);
+  if (losses) memcpy(losses, in.losses, 3 * sizeof(float));
+  stat_add(net, GA3C_STAT_TRAIN_SYNC_NS, now_ns() - t0);
+  return GA3C_OK;
 }
 
 int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
@@ -1096,6 +1113,11 @@ int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
     HIPCHK(hipHostMalloc((void**)&in.h_in, ((size_t)maxB * (XS + 1 + A)) * sizeof(float), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void**)&in.h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&in.ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&in.done, hipEventDisableTiming));
+    // the three loss sums are written by the kernel that completes them straight into pinned host memory (as p and v of a
+    // prediction are): no copy kernel behind the step
+    HIPCHK(hipHostMalloc((void**)&in.losses, 4 * sizeof(float), hipHostMallocDefault));
+    memset(in.losses, 0, 4 * sizeof(float));
   }
   bind_intake(t, t.in[0]);
   CHK(dmalloc(&t.dz, (size_t)maxB * A));
@@ -1106,10 +1128,6 @@ int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
   CHK(dmalloc(&t.dn1, (size_t)maxB * N1S));
   CHK(dmalloc(&t.slab2, (size_t)256 * SLAB2));   // conv2_dw: at most 256 sample groups
   CHK(dmalloc(&t.slab1, (size_t)512 * SLAB1));   // conv1_dw: at most 512 workgroups
-  // the three loss sums are written by the kernel that completes them straight into pinned host memory (as p and v of a
-  // prediction are): no copy kernel behind the step
-  HIPCHK(hipHostMalloc((void**)&t.losses, 4 * sizeof(float), hipHostMallocDefault));
-  memset(t.losses, 0, 4 * sizeof(float));
   CHK(dmalloc(&t.scales, 16));
   if (shared_grad) {
     t.grad = shared_grad;
@@ -1136,6 +1154,8 @@ void free_train_lane(TrainLane& t) {
     if (in.h_in) (void)hipHostFree(in.h_in);
     if (in.h_off) (void)hipHostFree(in.h_off);
     if (in.ready) (void)hipEventDestroy(in.ready);
+    if (in.done) (void)hipEventDestroy(in.done);
+    if (in.losses) (void)hipHostFree(in.losses);
     in.x = nullptr; in.xu8 = nullptr;
   }
   t.f.x = nullptr;
@@ -1143,7 +1163,6 @@ void free_train_lane(TrainLane& t) {
   free_fwd(t.f);
   for (float* p : {t.dz, t.dv, t.lossrow, t.dd1, t.dn2, t.dn1, t.slab2, t.slab1, t.scales})
     if (p) (void)hipFree(p);
-  if (t.losses) (void)hipHostFree(t.losses);
   if (t.owns_grad && t.grad) (void)hipFree(t.grad);
   if (t.h_out) (void)hipHostFree(t.h_out);
   if (t.gst) (void)hipStreamDestroy(t.gst);
@@ -1158,7 +1177,6 @@ int sync_all(ga3c_net* net) {
   for (TrainLane* t : net->xtr) HIPCHK(hipStreamSynchronize(t->st));
   {
     std::lock_guard<std::mutex> g(net->ready_mu);   // nothing is in flight: the newest weights are complete
-    net->must_wait[0] = net->must_wait[1] = false;
     net->cur.store(net->latest);   // (event_valid is irrelevant while cur == latest)
   }
   return GA3C_OK;
@@ -1323,7 +1341,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
       return GA3C_EHIP;                                                        \
     }                                                                          \
   } while (0)
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < ga3c_net::NBUF; ++i) {
     TRY(dmalloc(&net->theta[i], (size_t)net->n));
     TRY(dmalloc(&net->theta_pk[i], (size_t)PK_FLOATS));
     TRYHIP(hipEventCreateWithFlags(&net->theta_ready[i], hipEventDisableTiming));
@@ -1366,7 +1384,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     TRY(alloc_fwd(L->f, maxB, A));
     TRYHIP(hipHostMalloc((void**)&L->h_in, (size_t)maxB * XS * sizeof(float), hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
-    for (int k = 0; k < 2; ++k) TRYHIP(hipEventCreateWithFlags(&L->read_done[k], hipEventDisableTiming));
+    for (int k = 0; k < 3; ++k) TRYHIP(hipEventCreateWithFlags(&L->read_done[k], hipEventDisableTiming));
     TRYHIP(hipHostMalloc((void**)&L->h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
   }
   TRY(alloc_train_lane(net, net->tr, net->grad));
@@ -1399,7 +1417,7 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (L->h_in) (void)hipHostFree(L->h_in);
     if (L->h_out) (void)hipHostFree(L->h_out);
     if (L->h_off) (void)hipHostFree(L->h_off);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
       if (L->read_done[k]) (void)hipEventDestroy(L->read_done[k]);
     for (hipEvent_t e : {L->done, L->tm0, L->tm1})
       if (e) (void)hipEventDestroy(e);
@@ -1413,7 +1431,7 @@ int ga3c_net_destroy(ga3c_net* net) {
   }
   free_frames(net->fr);
   if (net->reg_host) (void)hipHostUnregister(net->reg_host);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < ga3c_net::NBUF; ++i) {
     if (net->theta[i]) (void)hipFree(net->theta[i]);
     if (net->theta_pk[i]) (void)hipFree(net->theta_pk[i]);
     if (net->theta_ready[i]) (void)hipEventDestroy(net->theta_ready[i]);
@@ -1521,14 +1539,16 @@ int ga3c_net_train(ga3c_net* net, const float* x, const float* y_r, const float*
                    float learning_rate, float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_train_inputs(net, s, x, false, y_r, a, batch); },
-                           [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
+                           [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
+                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
 }
 
 int ga3c_net_train_u8(ga3c_net* net, const uint8_t* x, const float* y_r, const float* a, int32_t batch,
                       float learning_rate, float beta, float* losses) {
   if (!net || !x || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_train_inputs(net, s, x, true, y_r, a, batch); },
-                           [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
+                           [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
+                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
 }
 
 int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const int64_t* offsets, int32_t offsets_u8,
@@ -1543,7 +1563,8 @@ int ga3c_net_evaluate(ga3c_net* net, const float* x, const uint8_t* x_u8, const 
         if (offsets) return launch_gather(net, offsets, batch, offsets_u8 != 0, s, y_r, a);
         return stage_train_inputs(net, s, x ? (const void*)x : (const void*)x_u8, x == nullptr, y_r, a, batch);
       },
-      [&](TrainLane& t) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); });
+      [&](TrainLane& t, Intake&) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); },
+      [](TrainLane&, Intake&) { return (int)GA3C_OK; });
 }
 
 int ga3c_net_register_host(ga3c_net* net, void* base, int64_t bytes) {
@@ -1594,7 +1615,8 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
   return with_staged_batch(
       net, batch,
       [&](Stage& s) { return launch_gather(net, offsets, batch, u8 != 0, s, y_r, a); },
-      [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
+      [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
+      [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
 }
 
 // ---- frame front-end ------------------------------------------------------------------------------------------
@@ -1834,7 +1856,8 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
   HIPCHK(hipSetDevice(net->cfg.device));
   if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_history_rows(net, s, agents, seqs, y_r, a, batch); },
-                           [&](TrainLane& t) { return train_body(net, t, batch, learning_rate, beta, losses); });
+                           [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
+                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
 }
 
 int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
@@ -1843,7 +1866,8 @@ int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t
   HIPCHK(hipSetDevice(net->cfg.device));
   if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_history_rows(net, s, agents, seqs, y_r, a, batch); },
-                           [&](TrainLane& t) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); });
+                           [&](TrainLane& t, Intake&) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); },
+      [](TrainLane&, Intake&) { return (int)GA3C_OK; });
 }
 
 int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed) {
