@@ -390,8 +390,8 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (net->fused_conv && B <= FUSED_CONV_MAX_B) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
     const size_t lds = CS_LDS_FLOATS * sizeof(float);
 #define CSTACK(T, U)                                                                                                \
-  hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, th + OFF_W1, th + OFF_B1, \
-                     th + OFF_W2, th + OFF_B2, f.n1, f.n2, B, f.src_off)
+  hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, net->theta_pk[idx] + PK_W1F, th + OFF_B1, \
+                     net->theta_pk[idx] + PK_W2F, th + OFF_B2, f.n1, f.n2, B, f.src_off)
     if (train) { if (f.x_u8) CSTACK(true, true); else CSTACK(true, false); }
     else { if (f.x_u8) CSTACK(false, true); else CSTACK(false, false); }
 #undef CSTACK
@@ -1488,8 +1488,7 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
   if (which == 0) {
     hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, net->tr.st, net->theta[net->latest] + OFF_WD,
                        net->theta_pk[net->latest]);
-    hipLaunchKernelGGL(pack_w2dx_kernel, dim3(32), dim3(256), 0, net->tr.st, net->theta[net->latest] + OFF_W2,
-                       net->theta_pk[net->latest] + PK_W2DX);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(48), dim3(256), 0, net->tr.st, net->theta[net->latest], net->theta_pk[net->latest]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(net->tr.st));
   }
@@ -2142,15 +2141,15 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "conv_stack_fwd") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
-                            t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
                             (const int64_t*)nullptr);
     } else if (k == "conv_stack_fwd_train") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<true, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
-                            t.ev0, t.ev1, 0, (const void*)t.f.x, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
                             (const int64_t*)nullptr);
     } else if (k == "conv_stack_fwd_u8") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
-                            t.ev0, t.ev1, 0, (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, th + OFF_W2, th + OFF_B2, t.f.n1, t.f.n2, B,
+                            t.ev0, t.ev1, 0, (const void*)t.f.xu8, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
                             (const int64_t*)nullptr);
     } else if (k == "dense1_fwd" || k == "dense1_fwd_frag") {
       const bool keep = net->d1f_tile;

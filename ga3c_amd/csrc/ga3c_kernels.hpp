@@ -362,9 +362,10 @@ __device__ __forceinline__ void cs_n1_pixel(int h, int m, int& row, int& col) {
   }
 }
 
+// w1f / w2f: the filter banks in forward fragment order (theta_pk + PK_W1F / PK_W2F)
 template <bool TRAIN, bool U8>
-__global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w1,
-                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+__global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w1f,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2f,
                                                              const float* __restrict__ b2, float* __restrict__ n1,
                                                              float* __restrict__ n2, int B,
                                                              const int64_t* __restrict__ src_off) {
@@ -396,8 +397,10 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   // the other waves' MFMAs.
   const int npx = xnr * C1_PW;                               // <= 4928 pixels -> at most 5 per thread
   GA3C_STAMP(0);
-  f32x4 sx[5], sw1, sw2[2];
-  sw1 = ld4(w1 + 4 * threadIdx.x);                           // W1[256][16] = 1024 float4 (first: it is stored first)
+  f32x4 sx[5];
+  // W1 (16 KB, needed first) then, behind the x rows, W2 (32 KB): packed, so they go global -> LDS as they lie
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1f + 4 * threadIdx.x),
+                                   (__attribute__((address_space(3))) void*)(wl1 + 4 * (threadIdx.x - lane)), 16, 0, 0);
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int idx = threadIdx.x + 1024 * i;
@@ -415,8 +418,10 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
       sx[i] = ok ? load_px<U8>(xs, sb, yy * IMG + xx) : zero4();
     }
   }
-  sw2[0] = ld4(w2 + 4 * threadIdx.x);                        // W2[256][32] = 2048 float4
-  sw2[1] = ld4(w2 + 4 * (threadIdx.x + 1024));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w2f + 4 * (threadIdx.x + 1024 * i)),
+                                     (__attribute__((address_space(3))) void*)(wl2 + 4 * (threadIdx.x + 1024 * i - lane)), 16, 0, 0);
   // nothing in the next two statements depends on the loads: they run while the loads are in flight
   for (int idx4 = threadIdx.x; idx4 < CS_N1_FLOATS / 4; idx4 += 1024) *reinterpret_cast<f32x4*>(&n1l[idx4 * 4]) = zero4();
   if (threadIdx.x < 256) {                                   // the divisions of the ragged map, once per pixel
@@ -425,10 +430,6 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
     pxmap[threadIdx.x] = (row << 8) | col;
   }
   GA3C_STAMP(1);
-  {
-    const int idx4 = threadIdx.x, k = idx4 >> 2, n = (idx4 & 3) * 4;
-    *reinterpret_cast<f32x4*>(&wl1[((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + n]) = sw1;
-  }
   if (U8) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -449,16 +450,13 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
       const int row = e >> 8, col = e & 255;
       const float* base = img + ((4 * (row - n1r0)) * C1_PW + 4 * col + g) * 4;
       // per pair of k-steps: 2 patch reads (16 B) + 8 filter fragments, fetched and pinned one pair ahead of their 8 MFMAs
-      f32x4 pa[2][2];
-      float pw[2][8];
-      auto load_pair = [&](int s, f32x4 (&a)[2], float (&w8)[8]) {
+      f32x4 pa[2][2], pw[2][2];
+      auto load_pair = [&](int s, f32x4 (&a)[2], f32x4 (&w2)[2]) {
         a[0] = ld4(base + ((s >> 1) * C1_PW + (s & 1) * 4) * 4);
         a[1] = ld4(base + (((s + 1) >> 1) * C1_PW + ((s + 1) & 1) * 4) * 4);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w8[k] = wl1[(s * 4 + k) * 64 + lane];
-        pin(a[0]); pin(a[1]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pin(w8[k]);
+        w2[0] = ld4(wl1 + (s * 64 + lane) * 4);
+        w2[1] = ld4(wl1 + ((s + 1) * 64 + lane) * 4);
+        pin(a[0]); pin(a[1]); pin(w2[0]); pin(w2[1]);
       };
       f32x4 acc0 = zero4(), acc1 = zero4();
       load_pair(0, pa[0], pw[0]);
@@ -467,8 +465,8 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
         if (s + 2 < 16) load_pair(s + 2, pa[((s >> 1) + 1) & 1], pw[((s >> 1) + 1) & 1]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc0 = mfma(pa[(s >> 1) & 1][0][t], pw[(s >> 1) & 1][t], acc0);
-          acc1 = mfma(pa[(s >> 1) & 1][1][t], pw[(s >> 1) & 1][4 + t], acc1);
+          acc0 = mfma(pa[(s >> 1) & 1][0][t], pw[(s >> 1) & 1][0][t], acc0);
+          acc1 = mfma(pa[(s >> 1) & 1][1][t], pw[(s >> 1) & 1][1][t], acc1);
         }
       }
       const int4 e4 = *reinterpret_cast<const int4*>(&pxmap[tile * 16 + 4 * g]);
@@ -482,11 +480,6 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
         }
       }
     }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx4 = threadIdx.x + 1024 * i, k = idx4 >> 3, n4 = (idx4 & 7) * 4;
-    *reinterpret_cast<f32x4*>(&wl2[(n4 >> 4) * 4096 + ((k >> 4) * 4 + (k & 3)) * 64 + ((k >> 2) & 3) * 16 + (n4 & 15)]) = sw2[i];
   }
   GA3C_STAMP(5);
   __syncthreads();
@@ -508,16 +501,13 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
       const int qq = q0 + (ml < c2npix ? ml : 0);
       const int i2 = qq / O2, j2 = qq - i2 * O2;
       const float* base = n1l + ((2 * (i2 - c2r0)) * C2_PW + 2 * j2) * C1 + 4 * g;
-      f32x4 pa[2][2];
-      float pw[2][8];
-      auto load_pair = [&](int s, f32x4 (&a)[2], float (&w8)[8]) {
+      f32x4 pa[2][2], pw[2][2];
+      auto load_pair = [&](int s, f32x4 (&a)[2], f32x4 (&w2)[2]) {
         a[0] = ld4(base + ((s >> 2) * C2_PW + (s & 3)) * C1);
         a[1] = ld4(base + (((s + 1) >> 2) * C2_PW + ((s + 1) & 3)) * C1);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w8[k] = wf[(s * 4 + k) * 64 + lane];
-        pin(a[0]); pin(a[1]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pin(w8[k]);
+        w2[0] = ld4(wf + (s * 64 + lane) * 4);
+        w2[1] = ld4(wf + ((s + 1) * 64 + lane) * 4);
+        pin(a[0]); pin(a[1]); pin(w2[0]); pin(w2[1]);
       };
       f32x4 acc0 = zero4(), acc1 = zero4();
       load_pair(0, pa[0], pw[0]);
@@ -526,8 +516,8 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
         if (s + 2 < 16) load_pair(s + 2, pa[((s >> 1) + 1) & 1], pw[((s >> 1) + 1) & 1]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc0 = mfma(pa[(s >> 1) & 1][0][t], pw[(s >> 1) & 1][t], acc0);
-          acc1 = mfma(pa[(s >> 1) & 1][1][t], pw[(s >> 1) & 1][4 + t], acc1);
+          acc0 = mfma(pa[(s >> 1) & 1][0][t], pw[(s >> 1) & 1][0][t], acc0);
+          acc1 = mfma(pa[(s >> 1) & 1][1][t], pw[(s >> 1) & 1][1][t], acc1);
         }
       }
       const float bv = b2[hh * 16 + r];
@@ -550,7 +540,21 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
 // dense1's packed copy (pk + FLAT*HID) and is kept current by rmsprop_kernel / slab_reduce's fused update /
 // pack_w2dx_kernel, so a workgroup stages a class with ONE 16-byte load per thread.
 constexpr int64_t PK_W2DX = (int64_t)FLAT * HID;             // offset of the packed conv12/w inside the pk buffer
-constexpr int PK_FLOATS = FLAT * HID + 256 * 32;
+// Behind it, the two conv filter banks in the order conv_stack_fwd's MFMAs consume them (round 3): element (k, n) of
+// conv11/w[256][16] at [s = k/16][lane = ((k/4)%4)*16 + n][t = k%4], element (k, o) of conv12/w[256][32] at
+// [column half o/16][s][lane = ((k/4)%4)*16 + o%16][t]: the four B fragments of a step are ONE 16-byte LDS read, and the
+// banks are staged by LDS-DMA as they lie (no pass through registers, no scattered ds_write).
+constexpr int64_t PK_W1F = PK_W2DX + 256 * 32;               // conv11/w, forward fragment order (4096 floats)
+constexpr int64_t PK_W2F = PK_W1F + 256 * 16;                // conv12/w, forward fragment order (8192 floats)
+constexpr int PK_FLOATS = FLAT * HID + 256 * 32 + 256 * 16 + 256 * 32;
+__host__ __device__ inline int w1f_packed_index(int i) {    // i = k*16 + n
+  const int n = i & 15, k = i >> 4;
+  return (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + n) << 2) | (k & 3);
+}
+__host__ __device__ inline int w2f_packed_index(int i) {    // i = k*32 + o
+  const int o = i & 31, k = i >> 5;
+  return (o >> 4) * 4096 + ((((k >> 4) * 64 + ((k >> 2) & 3) * 16 + (o & 15)) << 2) | (k & 3));
+}
 __host__ __device__ inline int w2dx_packed_index(int i) {   // i = index into W2[256][32] = ((u*4+v)*16 + c)*32 + o
   const int o = i & 31, k = i >> 5, c = k & 15, uv = k >> 4, u = uv >> 2, v = uv & 3;
   const int cls = (1 - (u & 1)) * 2 + (1 - (v & 1));
@@ -558,9 +562,20 @@ __host__ __device__ inline int w2dx_packed_index(int i) {   // i = index into W2
   const int t = o & 3, ln = ((o & 15) >> 2) * 16 + c;
   return cls * 2048 + (s * 64 + ln) * 4 + t;
 }
-__global__ __launch_bounds__(256) void pack_w2dx_kernel(const float* __restrict__ w2, float* __restrict__ pk2) {
+// the packed copies of a conv parameter at arena index i (conv11/w or conv12/w; no-op elsewhere)
+__device__ __forceinline__ void store_conv_packs(float* pk, int64_t i, float v) {
+  if (i >= OFF_W2 && i < OFF_B2) {
+    pk[PK_W2DX + w2dx_packed_index((int)(i - OFF_W2))] = v;
+    pk[PK_W2F + w2f_packed_index((int)(i - OFF_W2))] = v;
+  } else if (i < OFF_B1) {
+    pk[PK_W1F + w1f_packed_index((int)i)] = v;
+  }
+}
+// theta -> all packed copies of the two conv filter banks (pk = base of the packed buffer); grid 48 x 256
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ theta, float* __restrict__ pk) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 256 * 32) pk2[w2dx_packed_index(i)] = w2[i];
+  if (i < 256 * 32) store_conv_packs(pk, OFF_W2 + i, theta[OFF_W2 + i]);
+  else if (i < 256 * 32 + 256 * 16) store_conv_packs(pk, OFF_W1 + (i - 256 * 32), theta[OFF_W1 + (i - 256 * 32)]);
 }
 
 // ------------------------------------------------------------------ dense1 weight packing
@@ -2056,7 +2071,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabSet s0, SlabSet s
     if (UPD) {    // the conv parameters are stepped where their gradient is completed (off_w / off_b: arena offsets)
       const int64_t i = e < ss.nw ? ss.off_w + e : ss.off_b + (e - ss.nw);
       const float tn = fused_rmsprop(u, i, tot);
-      if (i >= OFF_W2 && i < OFF_B2) u.pk[PK_W2DX + w2dx_packed_index((int)(i - OFF_W2))] = tn;
+      store_conv_packs(u.pk, i, tn);
     }
   }
 }
@@ -2133,7 +2148,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(const float* __restrict__ 
       sc = scales[ti];
     }
     const float tn = rmsprop_one<CLIP, MOM>(i, theta_in, theta_out, ms, mom, grad, lr, one_minus_rho, mu, eps, sc);
-    if (i >= OFF_W2 && i < OFF_B2) pk_out[PK_W2DX + w2dx_packed_index((int)(i - OFF_W2))] = tn;
+    store_conv_packs(pk_out, i, tn);
   }
 }
 
