@@ -1,10 +1,11 @@
-// tools/native_agents.cpp -- development aid: the engine's ceiling when actors cost (almost) nothing.
+// tests/native/native_agents.cpp -- the engine's ceiling when actors cost (almost) nothing; also the 256-agent scale test
+// of BASELINE configs[3] / [4] (tests/test_gpu_engine_e2e.py) and the actor side of tools/engine_ceiling.py.
 // N threads act as agents 0..N-1 of a running Server through the C ABI of include/ga3c_host.h, exactly as ProcessAgent does
 // (ProcessAgent.py:102-107,117-162,175 of the reference): write a fresh uint8 state into the slot, submit, sleep on the
 // slot's futex for (p, v), draw the action from p, and every TIME_MAX steps ship a rollout (states, returns, actions) to the
 // training queue.  The "emulator" is a memcpy out of a pool of random frames, so what is measured is the transport, the
-// batching predictors / trainers and the GPU -- not Python.  Not part of the product or of the test suite.
-//   g++ -O2 -std=c++17 -pthread -I include -o tools/native_agents tools/native_agents.cpp -L ga3c_amd -lga3c_host -Wl,-rpath,$PWD/ga3c_amd
+// batching predictors / trainers and the GPU -- not Python.  Not part of the product.
+//   g++ -O2 -std=c++17 -pthread -I include -o tools/native_agents tests/native/native_agents.cpp -L ga3c_amd -lga3c_host -Wl,-rpath,$PWD/ga3c_amd
 //   tools/native_agents <segment name> <agents> <seconds> <train 0|1>
 #include <atomic>
 #include <chrono>

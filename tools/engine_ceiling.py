@@ -1,5 +1,5 @@
 """The engine's ceiling: the Server with its predictor / trainer threads and the HIP network, fed by NATIVE agent threads
-(tools/native_agents.cpp: the agent side of the C ABI, an "emulator" that is one memcpy) instead of Python ProcessAgents.
+(tests/native/native_agents.cpp: the agent side of the C ABI, an "emulator" that is one memcpy) instead of Python ProcessAgents.
 What is left is the transport, the batching threads and the GPU, with states crossing PCIe out of the registered segment.
 
     python tools/engine_ceiling.py --agents 256 --predictors 2 --trainers 2 --seconds 12 [--no-train]
@@ -21,7 +21,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def build_tool():
     exe = os.path.join(ROOT, "tools", "native_agents")
-    src = exe + ".cpp"
+    src = os.path.join(ROOT, "tests", "native", "native_agents.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", exe, src,
                                "-L", os.path.join(ROOT, "ga3c_amd"), "-lga3c_host", "-Wl,-rpath," + os.path.join(ROOT, "ga3c_amd")])
