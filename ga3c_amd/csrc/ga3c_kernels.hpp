@@ -351,6 +351,23 @@ constexpr int CS_N1_FLOATS = CS_N1ROWS * C2_PW * C1;          // 5376
 constexpr int CS_LDS_FLOATS = CS_X_FLOATS + CS_N1_FLOATS + 64 * 64 + 2 * 64 * 64 + 256;   // 37632 floats = 150,528 B
 constexpr int CS_C2CUT = 60;                                  // conv2 pixels [0,60) | [60,121)
 
+// (sample, half) of workgroup `id` of a 2 * B grid.  The two halves of a sample are EIGHT workgroups apart: blocks are dealt
+// round-robin over the 8 XCDs, so both halves run on the same XCD at the same time, and the 24 x rows (conv_bwd: n1 / dn2
+// rows) both of them need come out of HBM once and out of that XCD's L2 the second time (adjacent blocks, the round-2
+// mapping, put the halves on different XCDs: 20.4 MB fetched for 16.5 MB of states).  A placement hint only: any placement
+// computes the same result.  The last, partial group of samples (B % 8 of them) keeps its halves B % 8 apart.
+__device__ __forceinline__ void cs_sample_half(int id, int B, int& b, int& h) {
+  const int full = B >> 3, G = id >> 4;
+  if (G < full) {
+    b = 8 * G + (id & 7);
+    h = (id >> 3) & 1;
+  } else {
+    const int m = B - 8 * full, rr = id - 16 * full;      // m >= 1: id < 2 * B
+    h = rr >= m ? 1 : 0;
+    b = 8 * full + rr - h * m;
+  }
+}
+
 // the m-th n1 pixel of a half's ragged list -> (row, col)
 __device__ __forceinline__ void cs_n1_pixel(int h, int m, int& row, int& col) {
   if (h == 0) {
@@ -376,8 +393,9 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   float* wl2 = wl1 + 64 * 64;
   int* pxmap = reinterpret_cast<int*>(wl2 + 2 * 64 * 64);    // ragged n1 pixel list: m -> (row << 8) | col
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int b = blockIdx.x >> 1, h = blockIdx.x & 1;
-  if (b >= B) return;                                        // block-uniform guard: the grid is B * 2
+  if ((int)blockIdx.x >= 2 * B) return;                      // block-uniform guard: the grid is B * 2
+  int b, h;
+  cs_sample_half(blockIdx.x, B, b, h);
   // src_off: the states are not a dense batch but lie src_off[b] bytes behind x (transport slots in registered host
   // memory, or the device-side frame queues): the intake gather happens here, in the staging loads
   const void* xs = src_off ? static_cast<const void*>(static_cast<const char*>(x) + src_off[b]) : x;
@@ -1451,7 +1469,12 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   float* wds = dds + D1B_ROWS * D1B_DS;                     // [16][260]   Wd rows k0..k0+15
   float* n2s = wds + D1B_COLS * D1B_DS;                     // [16][132]   flat columns k0..k0+15 of the chunk's rows, transposed
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int k0 = blockIdx.x * D1B_COLS;
+  // column tile of this workgroup: tiles 2j and 2j + 1 -- the two halves of every 128-byte line of the flat rows -- are
+  // eight workgroups apart, i.e. on one XCD (blocks are dealt round-robin over the 8 XCDs), so each line of n2 comes out of
+  // HBM once instead of once per half (a placement hint only; the last two of the 242 tiles keep their own index)
+  const int bid = blockIdx.x;
+  const int tile = bid < 240 ? 16 * (bid >> 4) + 2 * (bid & 7) + ((bid >> 3) & 1) : bid;
+  const int k0 = tile * D1B_COLS;
   const int B = a.B;
   f32x4 accw[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};   // dWd tiles n-tile 2 wv, 2 wv + 1 (waves 0-7), two chains each
   float bs0 = 0.f, bs1 = 0.f;
@@ -1568,7 +1591,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q) gt[(4 * g + q) * HID + n0 + ni * 16 + r] = accw[ni][0][q] + accw[ni][1][q];
-    if (blockIdx.x == 0) {
+    if (tile == 0) {
       bs0 += __shfl_xor(bs0, 16, 64); bs0 += __shfl_xor(bs0, 32, 64);
       bs1 += __shfl_xor(bs1, 16, 64); bs1 += __shfl_xor(bs1, 32, 64);
       if (g == 0) {
@@ -1611,7 +1634,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     // the fragment-ordered copy dense1_fwd reads: rows 4 kq .. 4 kq + 3 of column n are 16 contiguous bytes there
     const int n = threadIdx.x & 255, kq = threadIdx.x >> 8;
     const f32x4 v = {gt[(4 * kq) * HID + n], gt[(4 * kq + 1) * HID + n], gt[(4 * kq + 2) * HID + n], gt[(4 * kq + 3) * HID + n]};
-    *reinterpret_cast<f32x4*>(a.upd.pk + ((size_t)blockIdx.x * HID + n) * 16 + 4 * kq) = v;
+    *reinterpret_cast<f32x4*>(a.upd.pk + ((size_t)tile * HID + n) * 16 + 4 * kq) = v;
   }
 }
 
@@ -1802,8 +1825,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   float* xb = dn1l + CB_DN1;                                 // [48][88][4]
   int* ptab = reinterpret_cast<int*>(xb + CB_XIMG);          // [4 classes][64 slots]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int h = blockIdx.x & 1, grp = blockIdx.x >> 1;
-  if (grp >= B) return;                                      // block-uniform
+  if ((int)blockIdx.x >= 2 * B) return;                      // block-uniform
+  int grp, h;
+  cs_sample_half(blockIdx.x, B, grp, h);                     // both halves of a sample on one XCD (see cs_sample_half)
   const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;   // conv2 pixels of this half
   const int c2r0 = h ? 5 : 0, n1org = 2 * c2r0 - 1;          // n1 image row 0 holds n1 row n1org
   const int r0 = h ? 10 : 0;                                 // first n1 row of its dn1 image; 11 rows, 4 bands
@@ -1998,8 +2022,8 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       redb[256 + (wv >> 2) * 64 + lane] = bs1;
     }
     __syncthreads();
-    float* o2 = slab2 + (size_t)blockIdx.x * SLAB2;
-    float* o1 = slab1 + (size_t)blockIdx.x * SLAB1;
+    float* o2 = slab2 + (size_t)(2 * grp + h) * SLAB2;      // slab order = (sample, half), whatever workgroup computed it:
+    float* o1 = slab1 + (size_t)(2 * grp + h) * SLAB1;      // the reduction's order, hence its bits, does not depend on the placement
     if (wv < 8) {                                            // (u, nh) = (wv & 3, wv >> 2): K half 0 (wave wv) + K half 1 (wave wv + 8)
       const int u = wv & 3, nh = wv >> 2;
 #pragma unroll
