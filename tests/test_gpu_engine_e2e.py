@@ -329,10 +329,11 @@ def test_engine_at_the_agent_counts_of_baseline_configs_3_and_4(tmp_path, monkey
         pps, tps, batch = (pb - pa) / (tb - ta), (sb_ - sa) / (tb - ta), (pb - pa) / max(bb - ba, 1)
         stats = srv.model.stats()
         srv.model.close()
-        # measured on one MI355X box: 430-600 k predictions/s, 3.3-4.6 k train steps/s, 19-60-row batches; the floors below
-        # are a third of that -- a collapse (58-67 k predictions/s in round 2's ring, 200 k in 4-row batches on five queues)
-        # is far below them
-        assert pps > 150e3 and tps > 1000 and batch > 12, (pps, tps, batch)
+        # measured on one MI355X box with a 16-core quota (tools/engine_ceiling.py, 10-s runs): 495-550 k predictions/s,
+        # 3.8-4.3 k train steps/s, 19-109-row batches; inside the whole suite, 8-s runs right behind other engine tests,
+        # as low as 240 k / 1.8 k / 9 rows.  The floors mark a collapse (58-67 k predictions/s in round 2's CAS-loop ring),
+        # not a performance target
+        assert pps > 100e3 and tps > 700 and batch > 4, (pps, tps, batch)
         assert stats["predict_weight_waits"] == 0                 # predictions never wait for a step in flight
         assert stats["train_rows"] / max(stats["train_calls"], 1) > 127
         assert all(t.is_alive() is False for t in srv.predictors + srv.trainers) and srv.failure is None

@@ -64,8 +64,16 @@ def main():
     srv = Server(max_agents=args.agents)
     snap = {}
 
+    def cgroup():
+        try:
+            d = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+            return int(d.get("usage_usec", 0)), int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+        except OSError:
+            return 0, 0, 0
+
     def take():
-        return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step,
+        return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step, "cg": cgroup(),
+                "eng": srv.model.stats() if hasattr(srv.model, "stats") else {},
                 "batches": sum(p.batches for p in srv.predictors),
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")},
                 "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive())}
@@ -93,7 +101,14 @@ def main():
     dt = b["t"] - a["t"]
     pred, batches = b["pred"] - a["pred"], max(1, b["batches"] - a["batches"])
     state_bytes = 84 * 84 if args.frame_queue_on_device else 84 * 84 * 4
+    eng = {k: b["eng"].get(k, 0) - a["eng"].get(k, 0) for k in b["eng"]}
+    pc, tc = max(eng.get("predict_calls", 0), 1), max(eng.get("train_calls", 0), 1)
+    engine = {"predict_us_per_call": {k[8:-3]: round(eng[k] / pc / 1e3, 1) for k in eng if k.startswith("predict_") and k.endswith("_ns")},
+              "train_us_per_call": {k[6:-3]: round(eng[k] / tc / 1e3, 1) for k in eng if k.startswith("train_") and k.endswith("_ns")},
+              "train_reader_waits_per_call": round(eng.get("train_reader_waits", 0) / tc, 3)}
     print(json.dumps({
+        "engine": engine, "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / dt, 2), "throttled_periods": b["cg"][1] - a["cg"][1],
+                                     "throttled_s": round((b["cg"][2] - a["cg"][2]) / 1e6, 2)},
         "agents": args.agents, "native_agents": True, "frame_queue_on_device": bool(args.frame_queue_on_device), "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
         "hogwild": bool(args.hogwild), "window_s": round(dt, 2), "host_cores": os.cpu_count(),
         "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
