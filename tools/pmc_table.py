@@ -60,7 +60,8 @@ ALGORITHMIC_MB = {
     # slabs read once: train steps reduce the 256 slab pairs of conv_bwd (256 x (4112 + 8224) floats), the per-kernel timer
     # the 512 + 128 slabs of the split kernels -- 12.63 MB either way
     "slab_reduce_kernel<false>": 256 * (4112 + 8224) * 4 / MB,
-    "slab_reduce_kernel<true>": 256 * (4112 + 8224) * 4 / MB + 5 * 12336 * 4 / MB,       # + RMSProp over the 12,336 conv parameters "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
+    "slab_reduce_kernel<true>": 256 * (4112 + 8224) * 4 / MB + 5 * 12336 * 4 / MB,       # + RMSProp over the 12,336 conv parameters
+    "rmsprop_kernel<false, false>": 5 * 4.0225 + WD + 0.03,
     "pack_wd_kernel": 2 * WD, "frame_frontend_kernel<3>": 256 * 157248 / MB,
 }
 
