@@ -5,6 +5,7 @@
 //    the two streams are multiplexed onto one hardware queue (in-order), j finishing at once means they are not.
 // 2. width: the spin kernel on n streams at once, one workgroup each: wall time / 300 us = how many turns the queues took.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -94,6 +95,21 @@ int main(int argc, char** argv) {
       for (int i = 0; i < n; ++i) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[i], 500LL, nullptr);
     CK(hipDeviceSynchronize());
     printf("  n = %d: %6.2f us per kernel per stream, %6.2f M kernels/s in all\n", n, (now_us() - t0) / 200.0, n * 200.0 / (now_us() - t0));
+  }
+  // hipExtAnyOrderLaunch: two 300-us kernels on ONE stream, the second launched without the ordering barrier
+  {
+    double best[2] = {1e30, 1e30};
+    for (int flag = 0; flag < 2; ++flag)
+      for (int rep = 0; rep < 5; ++rep) {
+        CK(hipDeviceSynchronize());
+        const double t0 = now_us();
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[0], SPIN, nullptr);
+        hipExtLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[0], nullptr, nullptr, flag ? hipExtAnyOrderLaunch : 0, SPIN, (int*)nullptr);
+        CK(hipStreamSynchronize(st[0]));
+        const double dt = now_us() - t0;
+        if (dt < best[flag]) best[flag] = dt;
+      }
+    printf("any-order launch: two 300-us kernels on one stream: %.1f us in order, %.1f us with hipExtAnyOrderLaunch\n", best[0], best[1]);
   }
   return 0;
 }
