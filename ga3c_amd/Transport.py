@@ -167,6 +167,12 @@ def unique_name(tag="ga3c"):
     return "/%s_%d_%d" % (tag, os.getpid(), int.from_bytes(os.urandom(3), "little"))
 
 
+def select_action_index(prediction, u):
+    """Index np.random.choice(n, p=prediction) returns when its uniform draw is `u` (ga3c_select_action: the call's own
+    float64 cdf / searchsorted arithmetic in C, a third of the numpy calls' time)."""
+    return nat.host_lib().ga3c_select_action(prediction.ctypes.data_as(nat.f32p), prediction.size, u)
+
+
 def accumulate_rewards_fork(rewards, gamma, terminal_reward, discounting=True, use_intermediate_reward=False):
     """ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84) through the C ABI, f64, bit-exact."""
     r = np.ascontiguousarray(rewards, dtype=np.float64)

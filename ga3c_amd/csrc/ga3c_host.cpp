@@ -734,6 +734,21 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
   return GA3C_H_OK;
 }
 
+int32_t ga3c_select_action(const float* p, int32_t n, double u) {
+  if (!p || n < 1) return 0;
+  if (n > MAXA) n = MAXA;
+  double cdf[MAXA];
+  double acc = 0.0;
+  for (int i = 0; i < n; ++i) {           // numpy: p converted to float64, cumsum = sequential adds
+    acc += (double)p[i];
+    cdf[i] = acc;
+  }
+  const double last = cdf[n - 1];
+  int idx = 0;
+  while (idx < n && !(u < cdf[idx] / last)) ++idx;     // searchsorted(side='right'): first index with cdf[idx] > u
+  return idx < n ? idx : n - 1;
+}
+
 int ga3c_pq_agent_idle(ga3c_shm* shm, int32_t agent) {
   if (!shm || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad agent id");
   AgentMeta* m = shm->meta(agent);

@@ -95,6 +95,11 @@ int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
 int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags);
 int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags);   /* predictor side */
 int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
+/* ProcessAgent.select_action = np.random.choice(n, p=prediction) (ProcessAgent.py:109-115) given the uniform that call
+ * would draw: float64 cumulative sum of the float32 probabilities, normalised by its last entry, first index whose
+ * cumulative value exceeds u (searchsorted side='right'), clamped to n - 1.  Bit-for-bit the arithmetic of numpy's
+ * RandomState.choice; the caller draws u with np.random.random_sample() so the global stream advances exactly as there. */
+int32_t ga3c_select_action(const float* p, int32_t n, double u);
 /* 1 when agent has no request in flight (every submit has been answered), 0 otherwise.  Server.add_agent (Server.py:106-110)
  * reuses the id of a removed agent only once this holds: an agent that was stopped while waiting may have left a request
  * behind, and a second submit on the same slot is refused while it is unanswered. */

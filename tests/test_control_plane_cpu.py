@@ -120,6 +120,27 @@ def test_select_action_draws_equal_numpy_choice(cfg):
         np.random.seed(trial)
         got = [ProcessAgent.select_action(actions, p) for _ in range(5)]
         assert got == want
+    # the C sampler (float32 vectors) and the numpy fallback (anything else) against np.random.choice: other action
+    # counts, vectors with exact zeros and with one dominant entry, many draws each
+    for n_act in (1, 4, 18, 64):
+        actions_n = np.arange(n_act)
+        for trial in range(40):
+            z = rng.normal(size=n_act) * (1 + trial % 7)
+            p64 = np.exp(z - z.max())
+            if n_act > 2 and trial % 3 == 0:
+                p64[rng.integers(0, n_act, size=n_act // 2)] = 0.0
+                p64[0] += 1e-3
+            p32 = (p64 / p64.sum()).astype(np.float32)
+            for p in (p32, p32.astype(np.float64)):
+                np.random.seed(1000 + trial)
+                want = [int(np.random.choice(actions_n, p=p / p.sum() if p.dtype == np.float64 else p)) for _ in range(20)] \
+                    if p.dtype == np.float32 else None
+                if want is None:       # float64 input: choice() insists on an exactly normalised vector; compare the two paths
+                    np.random.seed(1000 + trial)
+                    want = [ProcessAgent.select_action(actions_n, p32) for _ in range(20)]
+                np.random.seed(1000 + trial)
+                got = [ProcessAgent.select_action(actions_n, p) for _ in range(20)]
+                assert got == want, (n_act, trial, p.dtype)
     cfg.PLAY_MODE = True
     assert ProcessAgent.select_action(actions, np.array([0.1, 0.5, 0.2, 0.1, 0.05, 0.05], np.float32)) == 1
 
