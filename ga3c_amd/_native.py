@@ -119,6 +119,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_request_flags": (C.c_int, [C.c_void_p, u32p, C.c_int32, u32p]),
     "ga3c_pq_wait": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32]),
     "ga3c_select_action": (C.c_int32, [f32p, C.c_int32, C.c_double]),
+    "ga3c_frame_queue_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),   # (plane: address or bytes)
     "ga3c_pq_agent_idle": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),

@@ -734,6 +734,12 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
   return GA3C_H_OK;
 }
 
+int ga3c_frame_queue_push(const uint32_t* in, const uint8_t* plane, uint32_t* out, int32_t n) {
+  if (!in || !plane || !out || n < 0) return fail(GA3C_H_EINVAL, "bad argument");
+  for (int32_t i = 0; i < n; ++i) out[i] = (in[i] >> 8) | ((uint32_t)plane[i] << 24);
+  return GA3C_H_OK;
+}
+
 int32_t ga3c_select_action(const float* p, int32_t n, double u) {
   if (!p || n < 1) return 0;
   if (n > MAXA) n = MAXA;

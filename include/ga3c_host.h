@@ -95,6 +95,11 @@ int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
 int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags);
 int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags);   /* predictor side */
 int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
+/* Environment._update_frame_q + _get_current_state (Environment.py:62-74) for the 4-deep frame queue kept as one
+ * little-endian uint32 per pixel (byte c = frame c, oldest first): out[i] = (in[i] >> 8) | (plane[i] << 24), i < n.  The
+ * words of `out` are the [84,84,4] uint8 state with the new plane as its newest frame; `in` is left untouched (experiences
+ * of the running rollout still reference it).  The numpy expression took 6.8 us per agent step, this 0.5 us. */
+int ga3c_frame_queue_push(const uint32_t* in, const uint8_t* plane, uint32_t* out, int32_t n);
 /* ProcessAgent.select_action = np.random.choice(n, p=prediction) (ProcessAgent.py:109-115) given the uniform that call
  * would draw: float64 cumulative sum of the float32 probabilities, normalised by its last entry, first index whose
  * cumulative value exceeds u (searchsorted side='right'), clamped to n - 1.  Bit-for-bit the arithmetic of numpy's
