@@ -34,6 +34,11 @@ class Transport:
         # [max_agents, state_bytes] strided view over every agent's state
         self.agent_states = np.lib.stride_tricks.as_strided(self._raw[off0:], shape=(self.max_agents, self.state_bytes),
                                                             strides=(stride, 1), writeable=True)
+        self._views = {}
+        self._vcells = {}
+        self._submit = self._lib.ga3c_pq_submit_flags
+        # the same entry point with untyped pointer arguments: an address or a byref() goes through without a POINTER object
+        self._wait = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32)(("ga3c_pq_wait", self._lib))
         self._ro_off0 = self._lib.ga3c_shm_rollout_offset(self._h, 0)
         self._ro_stride = self._lib.ga3c_shm_rollout_stride(self._h)
 
@@ -61,15 +66,22 @@ class Transport:
     def close(self):
         if self._h:
             self._raw = self.agent_states = None
+            self._views = {}
             self._lib.ga3c_shm_close(self._h, 1 if self.owner else 0)
             self._h = None
 
-    # ---- agent side of predict
+    # ---- agent side of predict (once per agent step: views, the value cell and its reference are kept, the pointers go to
+    # C as plain addresses -- 9.3 -> 6.3 us of interpreter / ctypes time per round trip)
     def state_view(self, agent, dtype=np.uint8):
-        return self.agent_states[agent].view(dtype)
+        key = (agent, np.dtype(dtype).char)
+        view = self._views.get(key)
+        if view is None:
+            view = self._views[key] = self.agent_states[agent].view(dtype)
+        return view
 
     def submit(self, agent, flags=0):
-        return nat.check_host(self._lib.ga3c_pq_submit_flags(self._h, agent, flags), "ga3c_pq_submit_flags")
+        rc = self._submit(self._h, agent, flags)
+        return rc if rc in (0, TIMEOUT, CLOSED) else nat.check_host(rc, "ga3c_pq_submit_flags")
 
     def request_flags(self, ids):
         out = np.empty(ids.size, np.uint32)
@@ -79,9 +91,14 @@ class Transport:
 
     def wait(self, agent, timeout_ms=-1):
         p = np.empty(self.num_actions, np.float32)
-        v = C.c_float()
-        rc = nat.check_host(self._lib.ga3c_pq_wait(self._h, agent, nat.ptr(p), C.byref(v), timeout_ms), "ga3c_pq_wait")
-        return rc, p, v.value
+        cell = self._vcells.get(agent)
+        if cell is None:                       # one value cell per agent id (an id has one request in flight: one waiter)
+            v = C.c_float()
+            cell = self._vcells[agent] = (v, C.byref(v))
+        rc = self._wait(self._h, agent, p.ctypes.data, cell[1], timeout_ms)
+        if rc not in (0, TIMEOUT, CLOSED):
+            nat.check_host(rc, "ga3c_pq_wait")
+        return rc, p, cell[0].value
 
     def agent_idle(self, agent):
         """True when every request of `agent` has been answered (its id may then be handed to a new agent)."""
