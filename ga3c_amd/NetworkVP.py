@@ -107,10 +107,12 @@ class Network:
         cfg.log_epsilon = Config.LOG_EPSILON
         cfg.min_policy = Config.MIN_POLICY
         cfg.grad_clip_norm = Config.GRAD_CLIP_NORM
-        # a lane = stream + workspace of one prediction in flight; predictor threads beyond the lanes share them.  More lanes
-        # than predictor threads cost the ENGINE throughput (2 predictors on 4 lanes: 310 k predictions/s against 353 k on 2,
-        # profiles/README.md), so the default is one per configured predictor; GA3C_PREDICT_LANES overrides it
-        cfg.predict_lanes = int(predict_lanes or os.environ.get("GA3C_PREDICT_LANES") or max(1, Config.PREDICTORS))
+        # a lane = workspace + pinned staging of one prediction in flight (the lanes share two HIP streams: ga3c_net_create);
+        # predictor threads beyond the lanes wait for one.  One per configured predictor; with the dynamic adjustment on, NP
+        # walks (ThreadDynamicAdjustment.py:95-144), so there are at least four -- spare lanes cost nothing since round 3
+        # (round 2: a stream per lane, and the fifth stream landed on a lane's hardware queue).  GA3C_PREDICT_LANES overrides
+        default_lanes = max(1, Config.PREDICTORS, 4 if Config.DYNAMIC_SETTINGS else 1)
+        cfg.predict_lanes = int(predict_lanes or os.environ.get("GA3C_PREDICT_LANES") or default_lanes)
         if train_lanes is None:
             train_lanes = max(1, Config.TRAINERS) if Config.HOGWILD else 1
         cfg.train_lanes = int(train_lanes)

@@ -96,6 +96,7 @@ struct Lane {
   hipStream_t st = nullptr;   // lanes beyond net->lane_streams borrow the stream of lane (index % lane_streams): see ga3c_net_create
   bool owns_st = true;
   bool shared_st = false;     // another lane enqueues on `st` too: completion is waited for on `done`, not on the stream
+  int sidx = 0;               // which of the prediction streams `st` is (index into ga3c_net::stream_busy)
   hipEvent_t done = nullptr;
   hipEvent_t tm0 = nullptr, tm1 = nullptr;   // timing events of ga3c_net_time_predict_lanes
   Fwd f;
@@ -284,6 +285,7 @@ struct ga3c_net {
   float lanes_gpu_ms = 0.f;            // GPU-side span of the last ga3c_net_time_predict_lanes block (first start event .. last end event)
   int gather_max_blocks = 32;          // workgroups of the PCIe gather (GA3C_GATHER_BLOCKS; ga3c_kernels.hpp: gather_rows_kernel)
   int lane_streams = 2;                // HIP streams the prediction lanes are spread over (GA3C_LANE_STREAMS)
+  std::atomic<int> stream_busy[16];    // lanes at work per prediction stream: take_lane prefers a lane whose stream is idle
   // where the engine's calls spend their time (ga3c_net_stats): nanoseconds / counts, relaxed atomics
   std::atomic<int64_t> stat[GA3C_STAT_COUNT];
 };
@@ -908,18 +910,41 @@ struct PredictInFlight {   // one per prediction call / lane driver: how many la
   PredictInFlight& operator=(const PredictInFlight&) = delete;
 };
 
+// A free lane for one prediction call, locked.  With more lanes than prediction streams, a free lane whose stream no other
+// lane is using right now is preferred: two calls in flight then sit on two streams, not behind each other on one.
 Lane* take_lane(ga3c_net* net) {
   const unsigned start = net->rr.fetch_add(1);
-  for (size_t k = 0; k < net->lanes.size(); ++k) {
-    Lane* c = net->lanes[(start + k) % net->lanes.size()];
-    if (c->mu.try_lock()) return c;
+  const size_t n = net->lanes.size();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (size_t k = 0; k < n; ++k) {
+      Lane* c = net->lanes[(start + k) % n];
+      if (pass == 0 && net->stream_busy[c->sidx].load(std::memory_order_relaxed) != 0) continue;
+      if (c->mu.try_lock()) {
+        net->stream_busy[c->sidx].fetch_add(1, std::memory_order_relaxed);
+        return c;
+      }
+    }
   }
-  Lane* L = net->lanes[start % net->lanes.size()];
+  Lane* L = net->lanes[start % n];
   const int64_t t0 = now_ns();
   L->mu.lock();
   stat_add(net, GA3C_STAT_PREDICT_LANE_WAIT_NS, now_ns() - t0);
+  net->stream_busy[L->sidx].fetch_add(1, std::memory_order_relaxed);
   return L;
 }
+
+// releases what take_lane took (the lane's mutex and its claim on the stream)
+struct LaneGuard {
+  ga3c_net* net;
+  Lane* L;
+  LaneGuard(ga3c_net* n, Lane* l) : net(n), L(l) {}
+  ~LaneGuard() {
+    net->stream_busy[L->sidx].fetch_sub(1, std::memory_order_relaxed);
+    L->mu.unlock();
+  }
+  LaneGuard(const LaneGuard&) = delete;
+  LaneGuard& operator=(const LaneGuard&) = delete;
+};
 
 // wait until everything lane L has enqueued is done (L's mutex is held)
 int lane_wait(Lane* L) {
@@ -960,7 +985,7 @@ int predict_common(ga3c_net* net, const void* x, bool u8, int B, float* p, float
   HIPCHK(hipSetDevice(net->cfg.device));
   PredictInFlight inflight(net);
   Lane* L = take_lane(net);
-  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  LaneGuard guard(net, L);
   if (u8) {
     const size_t nb = (size_t)B * XS;
     if (is_pinned(x)) {
@@ -1268,6 +1293,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (!net) return fail(GA3C_EINVAL, "out of host memory");
   net->cfg = *cfg;
   for (auto& c : net->stat) c.store(0);
+  for (auto& c : net->stream_busy) c.store(0);
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
@@ -1370,6 +1396,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     Lane* L = new (std::nothrow) Lane();
     if (!L) { ga3c_net_destroy(net); return fail(GA3C_EINVAL, "out of host memory"); }
     net->lanes.push_back(L);
+    L->sidx = i % net->lane_streams;
     if (i < net->lane_streams) {
       TRYHIP(hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking));
     } else {
@@ -1603,7 +1630,7 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
   HIPCHK(hipSetDevice(net->cfg.device));
   PredictInFlight inflight(net);
   Lane* L = take_lane(net);
-  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  LaneGuard guard(net, L);
   CHK(stage_offsets(net, offsets, batch, u8 != 0, L->h_off));
   return finish_predict(net, L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, p, v, z);
 }
@@ -1776,7 +1803,7 @@ int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, flo
   }
   PredictInFlight inflight(net);
   Lane* L = take_lane(net);
-  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  LaneGuard guard(net, L);
   for (int i = 0; i < n; ++i) L->h_off[i] = (int64_t)agents[i] * XS;
   return finish_predict(net, L, n, STEP_QUEUES, p, v, z);
 }
@@ -1791,7 +1818,7 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   HIPCHK(hipSetDevice(net->cfg.device));
   PredictInFlight inflight(net);
   Lane* L = take_lane(net);
-  std::lock_guard<std::mutex> guard(L->mu, std::adopt_lock);
+  LaneGuard guard(net, L);
   // per-call argument arrays, carved out of the lane's (otherwise idle) pinned input staging and read by the kernels in place
   int32_t* h_ag = reinterpret_cast<int32_t*>(L->h_in);
   int32_t* h_slot = h_ag + net->maxB;
