@@ -134,8 +134,16 @@ class Environment:
             nat.check_host(nat.host_lib().ga3c_frame_preprocess(nat.ptr(self.frame, nat.u8p), fh, fw, fc, h, w,
                                                                 nat.ptr(frame, nat.u8p)), "ga3c_frame_preprocess")
         else:
-            plane_arg = self.rng.bytes(h * w)           # (bytes go to C as they are: no address lookup)
-            frame = np.frombuffer(plane_arg, np.uint8).reshape(h, w) if self.on_device else None
+            if (h * w) % 8 == 0:
+                # the same byte stream as rng.bytes(h * w) -- both hand out PCG64's 64-bit outputs low half first -- drawn
+                # as whole words in one vectorised call: 5 us instead of 13 (equality pinned in tests/test_control_plane_cpu.py)
+                raw = self.rng.bit_generator.random_raw(h * w // 8)
+                plane_arg = raw.ctypes.data
+                frame = raw.view(np.uint8).reshape(h, w) if self.on_device else None
+                self._keep = raw                        # the plane's bytes must outlive the push below
+            else:
+                plane_arg = self.rng.bytes(h * w)       # (bytes go to C as they are: no address lookup)
+                frame = np.frombuffer(plane_arg, np.uint8).reshape(h, w) if self.on_device else None
             if self.on_device:                            # ready-made plane, queue kept on the device
                 self.frame = frame
                 self.frames_queued += 1
