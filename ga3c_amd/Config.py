@@ -82,6 +82,7 @@ class Config:
     ZERO_COPY = True                    # GPU gathers states straight from the registered shm transport
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often
     NATIVE_PREDICTOR = True             # ThreadPredictor's loop in native code (ga3c_pq_serve) when ZERO_COPY is on
+    PIPELINED_PREDICTOR = True          # ... answering batch k beside the GPU's work on batch k+1 (ga3c_pq_serve_pipelined)
     NATIVE_TRAINER = True               # ThreadTrainer's batch assembly in one native call (ga3c_tq_collect) when ZERO_COPY is on
     PREDICTION_LINGER_US = 0            # > 0: a predictor holding fewer than PREDICTION_LINGER_BATCH requests after its
     PREDICTION_LINGER_BATCH = 0         # greedy drain keeps collecting this long (the reference never waits: 0)

@@ -331,6 +331,11 @@ class Network:
         (ga3c_pq_serve, include/ga3c_host.h) calls for every batch instead of predict_offsets()."""
         return C.cast(self._lib.ga3c_net_predict_gather, C.c_void_p).value, self._h, int(self._transport_u8)
 
+    def gather_entries_pipelined(self):
+        """(addresses of ga3c_net_predict_gather_begin / _end, engine handle, u8 flag) for ga3c_pq_serve_pipelined."""
+        return (C.cast(self._lib.ga3c_net_predict_gather_begin, C.c_void_p).value,
+                C.cast(self._lib.ga3c_net_predict_gather_end, C.c_void_p).value, self._h, int(self._transport_u8))
+
     def predict_offsets(self, offsets):
         """offsets: int64[B] byte offsets of the states inside the registered segment."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

@@ -39,8 +39,14 @@ class ThreadPredictor(Thread):
     def _run_native(self, entry, handle, u8):
         t, st = self.transport, nat.ServeStats()
         self.native = True
+        # answering batch k beside the GPU's work on batch k+1 (ga3c_pq_serve_pipelined) when the model offers the split call
+        split = getattr(self.server.model, "gather_entries_pipelined", None) if getattr(Config, "PIPELINED_PREDICTOR", True) else None
+        begin_end = split() if split else None
         while not self.exit_flag:
-            rc = t.serve(entry, handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+            if begin_end:
+                rc = t.serve_pipelined(begin_end[0], begin_end[1], handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+            else:
+                rc = t.serve(entry, handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
             self.batches, self.served = st.batches, st.served
             self.seconds = {"pop": st.ns_pop * 1e-9, "predict": st.ns_predict * 1e-9, "respond": st.ns_respond * 1e-9}
             if rc < 0:

@@ -119,6 +119,13 @@ class Transport:
         rc = self._lib.ga3c_pq_serve(self._h, entry, net_handle, int(u8), int(max_batch), int(slice_ms), C.addressof(stats))
         return nat.check_host(rc, "ga3c_pq_serve")
 
+    def serve_pipelined(self, begin, end, net_handle, u8, max_batch, slice_ms, stats):
+        """One time slice of the native predictor loop that answers batch k beside the GPU's work on batch k+1
+        (ga3c_pq_serve_pipelined); `begin` / `end` are the addresses of ga3c_net_predict_gather_begin / _end."""
+        rc = self._lib.ga3c_pq_serve_pipelined(self._h, begin, end, net_handle, int(u8), int(max_batch), int(slice_ms),
+                                               C.addressof(stats))
+        return nat.check_host(rc, "ga3c_pq_serve_pipelined")
+
     def set_linger(self, linger_us, min_batch):
         nat.check_host(self._lib.ga3c_pq_set_linger(self._h, int(linger_us), int(min_batch)), "ga3c_pq_set_linger")
 

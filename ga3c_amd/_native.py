@@ -64,6 +64,8 @@ HIP_SIGNATURES = {
     "ga3c_net_register_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ga3c_net_unregister_host": (C.c_int, [C.c_void_p]),
     "ga3c_net_predict_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, f32p, f32p, f32p]),
+    "ga3c_net_predict_gather_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, i32p]),
+    "ga3c_net_predict_gather_end": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p]),
     "ga3c_net_train_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32, f32p, f32p, C.c_int32, C.c_float,
                                         C.c_float, f32p]),
     "ga3c_net_frames_config": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
@@ -119,6 +121,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_request_flags": (C.c_int, [C.c_void_p, u32p, C.c_int32, u32p]),
     "ga3c_pq_wait": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32]),
     "ga3c_select_action": (C.c_int32, [f32p, C.c_int32, C.c_double]),
+    "ga3c_pq_serve_pipelined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_frame_queue_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),   # (plane: address or bytes)
     "ga3c_pq_agent_idle": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),

@@ -1635,6 +1635,56 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
   return finish_predict(net, L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, p, v, z);
 }
 
+int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket) {
+  if (!net || !offsets || !ticket) return fail(GA3C_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(net->cfg.device));
+  Lane* L = take_lane(net);                                  // stays taken until ga3c_net_predict_gather_end
+  net->predict_inflight.fetch_add(1, std::memory_order_relaxed);
+  auto give_back = [&]() {
+    net->predict_inflight.fetch_sub(1, std::memory_order_relaxed);
+    net->stream_busy[L->sidx].fetch_sub(1, std::memory_order_relaxed);
+    L->mu.unlock();
+  };
+  int rc = stage_offsets(net, offsets, batch, u8 != 0, L->h_off);
+  if (rc == GA3C_OK) {
+    TraceRange range("ga3c.predict.begin");
+    const int64_t t0 = now_ns();
+    float* hp = L->h_out;
+    float* hv = hp + (size_t)net->maxB * net->A;
+    rc = lane_forward(net, *L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, hp, hv);
+    stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, now_ns() - t0);
+  }
+  if (rc != GA3C_OK) {
+    give_back();
+    return rc;
+  }
+  for (size_t i = 0; i < net->lanes.size(); ++i)
+    if (net->lanes[i] == L) *ticket = (int32_t)i;
+  return GA3C_OK;
+}
+
+int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, float* p, float* v) {
+  if (!net || !p || !v) return fail(GA3C_EINVAL, "null argument");
+  if (ticket < 0 || ticket >= (int32_t)net->lanes.size()) return fail(GA3C_EINVAL, "bad ticket %d", ticket);
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
+  Lane* L = net->lanes[(size_t)ticket];
+  const int64_t t0 = now_ns();
+  const int rc = lane_wait(L);
+  if (rc == GA3C_OK) {
+    const float* hp = L->h_out;
+    const float* hv = hp + (size_t)net->maxB * net->A;
+    memcpy(p, hp, (size_t)batch * net->A * sizeof(float));
+    memcpy(v, hv, (size_t)batch * sizeof(float));
+    stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
+    stat_add(net, GA3C_STAT_PREDICT_ROWS, batch);
+    stat_add(net, GA3C_STAT_PREDICT_SYNC_NS, now_ns() - t0);
+  }
+  net->predict_inflight.fetch_sub(1, std::memory_order_relaxed);
+  net->stream_busy[L->sidx].fetch_sub(1, std::memory_order_relaxed);
+  L->mu.unlock();
+  return rc;
+}
+
 int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses) {
   if (!net || !offsets || !y_r || !a) return fail(GA3C_EINVAL, "null argument");

@@ -844,6 +844,74 @@ int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_
   }
 }
 
+int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_end_fn end, void* net, int32_t u8,
+                            int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* st) {
+  if (!shm || !begin || !end || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
+  Header* h = shm->hdr();
+  const int A = h->cfg.num_actions;
+  // two batches in flight: `cur` is being computed while `prev` (results already fetched) is answered
+  std::vector<uint32_t> ids[2] = {std::vector<uint32_t>((size_t)max_batch), std::vector<uint32_t>((size_t)max_batch)};
+  std::vector<float> p[2] = {std::vector<float>((size_t)max_batch * A), std::vector<float>((size_t)max_batch * A)};
+  std::vector<float> v[2] = {std::vector<float>((size_t)max_batch), std::vector<float>((size_t)max_batch)};
+  std::vector<int64_t> offs((size_t)max_batch);
+  int cur = 0, n_prev = 0;
+  const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
+  auto answer_prev = [&]() -> int {
+    if (n_prev == 0) return GA3C_H_OK;
+    const int64_t t0 = now_ns();
+    const int rr = ga3c_pq_respond(shm, ids[1 - cur].data(), n_prev, p[1 - cur].data(), v[1 - cur].data());
+    st->ns_respond += now_ns() - t0;
+    n_prev = 0;
+    return rr;
+  };
+  for (;;) {
+    const int64_t t0 = now_ns();
+    const int64_t left_ms = (t_end - t0 + 999999) / 1000000;
+    if (left_ms <= 0) return answer_prev();                  // nothing is held across slices
+    // with a batch waiting to be answered only requests that are ALREADY queued are taken; otherwise sleep for one
+    const int n = ga3c_pq_pop_batch(shm, ids[cur].data(), max_batch, n_prev ? 0 : (int)left_ms);
+    const int64_t t1 = now_ns();
+    st->ns_pop += t1 - t0;
+    if (n < 0 && n != GA3C_H_ETIMEOUT) {
+      (void)answer_prev();
+      return n;
+    }
+    int ticket = -1;
+    if (n > 0) {
+      for (int i = 0; i < n; ++i) {
+        if (ids[cur][i] >= (uint32_t)h->cfg.max_agents) {
+          (void)answer_prev();
+          return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[cur][i]);
+        }
+        offs[i] = h->agents_off + (int64_t)ids[cur][i] * h->agent_stride;
+      }
+      const int rc = begin(net, offs.data(), n, u8, &ticket);
+      if (rc < 0) {
+        (void)answer_prev();
+        return fail(GA3C_H_ECALLBACK, "predict callback (begin) failed with %d on a batch of %d", rc, n);
+      }
+    }
+    const int64_t t2 = now_ns();
+    st->ns_predict += t2 - t1;
+    const int rr = answer_prev();                            // beside the GPU's work on `cur`
+    if (n > 0) {
+      const int64_t t3 = now_ns();
+      const int rc = end(net, ticket, n, p[cur].data(), v[cur].data());
+      st->ns_predict += now_ns() - t3;
+      if (rc < 0) return fail(GA3C_H_ECALLBACK, "predict callback (end) failed with %d on a batch of %d", rc, n);
+      st->batches += 1;
+      st->served += n;
+      if (n > st->largest_batch) st->largest_batch = n;
+      n_prev = n;
+      cur = 1 - cur;
+    }
+    if (rr < 0) {
+      (void)answer_prev();
+      return rr;
+    }
+  }
+}
+
 int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, int32_t max_batch, int32_t slice_ms,
                          ga3c_serve_stats* st) {
   if (!shm || !serve || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");

@@ -132,6 +132,14 @@ typedef struct ga3c_serve_stats {
 } ga3c_serve_stats;
 int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
                   int32_t slice_ms, ga3c_serve_stats* stats);
+/* The same loop with the answering overlapped with the GPU: while requests are queued, batch k+1 is popped and its step
+ * ENQUEUED (`begin`) before batch k is answered, so the ~1.6 us per agent that waking it costs (a futex wake each) run beside
+ * the GPU's work on the next batch instead of in front of it; with nothing queued batch k is answered at once, as above.
+ * `begin` / `end` have the signatures of ga3c_net_predict_gather_begin / _end (include/ga3c_abi.h).  Same return values. */
+typedef int (*ga3c_predict_begin_fn)(void* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket);
+typedef int (*ga3c_predict_end_fn)(void* net, int32_t ticket, int32_t batch, float* p, float* v);
+int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_end_fn end, void* net, int32_t u8,
+                            int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* stats);
 /* The same loop for raw-frame requests (ga3c_pq_submit_flags): `serve` has the signature of ga3c_net_serve_frames
  * (include/ga3c_abi.h) and gets the popped slots' offsets, agent ids and request flags; stats->served counts the
  * predictions made (requests without GA3C_REQ_NO_PREDICT). */

@@ -538,6 +538,120 @@ def test_native_serve_loop_batches_and_routes_like_the_reference_trace(mods, gol
         t.close()
 
 
+@pytest.mark.parametrize("key", ["predictor_128", "predictor_32"])
+def test_pipelined_serve_loop_batches_routes_and_overlaps(mods, golden_dir, key):
+    """ga3c_pq_serve_pipelined: the same batching as the reference's trace and every agent its own answer, and -- while
+    requests are queued -- batch k+1 is BEGUN before batch k is answered (the answering runs beside the GPU), while the last
+    batch, with nothing queued behind it, is answered at once."""
+    import ctypes as C
+    nat, tp, Config = mods
+    from ThreadPredictor import ThreadPredictor
+    g = json.load(open(os.path.join(golden_dir, "batcher_traces.json")))[key]
+    n_req, sdim, n_act = g["n_requests"], g["state_dim"], 6
+    t = tp.Transport.create(tp.unique_name("t_pipe"), n_req, n_act, sdim, 4, 6)
+    events, held = [], {}
+
+    def answered():          # agents whose answer has arrived so far
+        return sum(1 for i in range(n_req) if t.agent_idle(i))
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_int32))
+    def begin(net, offsets, batch, u8, ticket):
+        events.append(("begin", batch, answered()))
+        held[len(events)] = [int(offsets[i]) for i in range(batch)]
+        ticket[0] = len(events)
+        return 0
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+    def end(net, ticket, batch, p, v):
+        offs = held.pop(ticket)
+        assert len(offs) == batch
+        for i, off in enumerate(offs):
+            row = t._raw[off: off + sdim]
+            for a in range(n_act):
+                p[i * n_act + a] = float(row[a])
+            v[i] = float(row.astype(np.float32).sum())
+        events.append(("end", batch, answered()))
+        return 0
+
+    class _Model:
+        def gather_entry(self):
+            return None, None, 1
+
+        def gather_entries_pipelined(self):
+            return C.cast(begin, C.c_void_p).value, C.cast(end, C.c_void_p).value, None, 1
+
+    class _Server:
+        zero_copy = True
+        model = _Model()
+
+    try:
+        rng = np.random.default_rng(g["seed"])
+        states = rng.integers(0, 256, size=(n_req, sdim)).astype(np.uint8)
+        for i in range(n_req):
+            t.state_view(i)[:] = states[i]
+            t.submit(i)
+        Config.PREDICTION_BATCH_SIZE = g["batch_max"]
+        th = ThreadPredictor(_Server(), 0, (sdim,), t)
+        th.start()
+        deadline = time.time() + 10
+        while answered() < n_req and time.time() < deadline:
+            time.sleep(0.01)
+        th.exit_flag = True
+        th.join(5)
+        assert th.native and not th.is_alive() and not held
+        begins = [e for e in events if e[0] == "begin"]
+        assert [b[1] for b in begins] == g["batch_sizes"] and th.batches == len(begins) and th.served == n_req
+        # batch k+1 is begun while batch k is still unanswered: at begin k+1 only the batches before k have been answered
+        done = 0
+        for k, b in enumerate(begins):
+            assert b[2] == (done - begins[k - 1][1] if k else 0), (k, b, done)
+            done += b[1]
+        for i in range(n_req):
+            rc, p, v = t.wait(i, 1000)
+            assert rc == 0
+            assert v == float(states[i].astype(np.float32).sum())
+            assert p.tolist() == states[i, :n_act].astype(np.float32).tolist()
+    finally:
+        Config.PREDICTION_BATCH_SIZE = 128
+        t.shutdown()
+        t.close()
+
+
+def test_pipelined_serve_loop_reports_a_failing_engine_and_still_answers_what_it_holds(mods):
+    import ctypes as C
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_pipe_err"), 4, 6, 64, 4, 6)
+    calls = []
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_int32))
+    def begin(net, offsets, batch, u8, ticket):
+        calls.append(batch)
+        ticket[0] = 0
+        return -2 if len(calls) > 1 else 0
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+    def end(net, ticket, batch, p, v):
+        for i in range(batch):
+            v[i] = 7.0
+        return 0
+
+    b, e = C.cast(begin, C.c_void_p).value, C.cast(end, C.c_void_p).value
+    try:
+        st = nat.ServeStats()
+        assert t.serve_pipelined(b, e, None, 1, 1, 20, st) == 0          # idle slice: plain return
+        t.submit(1)
+        t.submit(2)                                                     # batch size 1: agent 1 is held when agent 2's begin fails
+        with pytest.raises(RuntimeError, match="begin\\) failed with -2"):
+            t.serve_pipelined(b, e, None, 1, 1, 200, st)
+        rc, _, v = t.wait(1, 1000)
+        assert rc == 0 and v == 7.0                                      # the batch that had been computed is answered
+        assert not t.agent_idle(2)
+        t.shutdown()
+        assert t.serve_pipelined(b, e, None, 1, 1, 20, st) == -4         # closed
+    finally:
+        t.close()
+
+
 def test_native_serve_loop_reports_a_failing_engine(mods):
     import ctypes as C
     nat, tp, Config = mods
