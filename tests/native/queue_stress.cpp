@@ -25,6 +25,18 @@ static int fake_predict_rows(void*, const int64_t* offsets, int32_t batch, int32
   }
   return 0;
 }
+// ... and for ga3c_net_predict_gather_begin / _end in the pipelined loop (ga3c_pq_serve_pipelined): begin keeps the batch's
+// offsets under a ticket (per calling thread: a thread has one batch begun at a time), end computes the answers
+static thread_local int64_t t_offs[8];
+static int fake_begin(void*, const int64_t* offsets, int32_t batch, int32_t, int32_t* ticket) {
+  for (int i = 0; i < batch; ++i) t_offs[i] = offsets[i];
+  *ticket = batch;
+  return 0;
+}
+static int fake_end(void*, int32_t ticket, int32_t batch, float* p, float* v) {
+  if (ticket != batch) return -1;
+  return fake_predict_rows(nullptr, t_offs, batch, 1, p, v, nullptr);
+}
 #define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s line %d\n", #c, __LINE__); failures++; } } while (0)
 
 int main(int argc, char** argv) {
@@ -56,6 +68,15 @@ int main(int argc, char** argv) {
     std::memset(&st, 0, sizeof st);
     int rc;
     while ((rc = ga3c_pq_serve(shm, fake_predict_rows, nullptr, 1, 8, 20, &st)) == GA3C_H_OK) {}
+    REQUIRE(rc == GA3C_H_ECLOSED);
+    REQUIRE(st.largest_batch <= 8);
+    served += st.served;
+  });
+  th.emplace_back([&] {     // ... and one the pipelined native loop (answers batch k after batch k+1 has been begun)
+    ga3c_serve_stats st;
+    std::memset(&st, 0, sizeof st);
+    int rc;
+    while ((rc = ga3c_pq_serve_pipelined(shm, fake_begin, fake_end, nullptr, 1, 8, 20, &st)) == GA3C_H_OK) {}
     REQUIRE(rc == GA3C_H_ECLOSED);
     REQUIRE(st.largest_batch <= 8);
     served += st.served;
