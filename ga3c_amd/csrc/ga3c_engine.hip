@@ -97,6 +97,7 @@ struct Lane {
   bool owns_st = true;
   bool shared_st = false;     // another lane enqueues on `st` too: completion is waited for on `done`, not on the stream
   int sidx = 0;               // which of the prediction streams `st` is (index into ga3c_net::stream_busy)
+  std::atomic<bool> begun{false};   // taken by ga3c_net_predict_gather_begin, to be given back by _end
   hipEvent_t done = nullptr;
   hipEvent_t tm0 = nullptr, tm1 = nullptr;   // timing events of ga3c_net_time_predict_lanes
   Fwd f;
@@ -128,6 +129,7 @@ struct Intake {
   hipEvent_t done = nullptr;    // recorded on the train stream behind the step that trained this batch
   float* losses = nullptr;      // pinned: the three loss sums of that step, written by the kernel that completes them
   int wbuf = -1;                // the weight buffer that step wrote (-1: none, or updated in place)
+  uint64_t wbuf_seq = 0;        // ... and the step number it carried then (ga3c_net::wseq)
   bool x_u8 = false;
 };
 
@@ -157,6 +159,7 @@ struct TrainLane {
   bool stepped = false;     // the backward pass has applied RMSProp itself (FusedUpd) into theta[stepped_other]
   int stepped_other = 0;
   int wrote = -1;           // the weight buffer the step enqueued last on this lane wrote (publish_other_buffer)
+  uint64_t wrote_seq = 0;   // ... and that step's number
 };
 
 // K slices of dense1_fwd.  Its grid is (row blocks) x (2 column halves) x (slices), every slice a partial slab that
@@ -636,6 +639,11 @@ int claim_other_buffer(ga3c_net* net, TrainLane& t, int* idx_out, int* other_out
       stat_add(net, GA3C_STAT_TRAIN_READER_WAITS, 1);
     }
   }
+  // From here until the step is published the buffer holds no weights anyone may adopt: it may be the in-between buffer of
+  // steps enqueued back to back (newer than `cur`, its old step long finished), which adopt_finished would otherwise hand to
+  // a prediction that this step, already enqueued, does not wait for.
+  net->wseq[other] = 0;
+  net->event_valid[other] = false;
   *idx_out = idx;
   *other_out = other;
   return GA3C_OK;
@@ -652,15 +660,17 @@ int publish_other_buffer(ga3c_net* net, TrainLane& t, int other) {
   net->wseq[other] = ++net->wcount;
   net->step.fetch_add(1);
   t.wrote = other;
+  t.wrote_seq = net->wseq[other];
   return GA3C_OK;
 }
 
-// the step that wrote theta[buf] is known to have finished (its caller has waited for it): predictions may read it
-void adopt_buffer(ga3c_net* net, int buf) {
+// the step number `seq` that wrote theta[buf] is known to have finished (its caller has waited for it): predictions may read
+// it -- unless a later step has claimed the buffer since (wseq differs: that step's own waiter will hand it over)
+void adopt_buffer(ga3c_net* net, int buf, uint64_t seq) {
   if (buf < 0) return;
   std::shared_lock<std::shared_mutex> lk(net->wmu);
   std::lock_guard<std::mutex> g(net->ready_mu);
-  if (net->wseq[buf] > net->wseq[net->cur.load()]) net->cur.store(buf);
+  if (net->wseq[buf] == seq && seq > net->wseq[net->cur.load()]) net->cur.store(buf);
 }
 
 // gradients of the batch staged in train lane `t` -> t.grad (the lane's mutex is held by the caller).  will_apply: the
@@ -1091,6 +1101,7 @@ int train_enqueue(ga3c_net* net, TrainLane& t, Intake& in, int B, float lr, floa
   CHK(train_grads(net, t, B, beta, true, lr));
   CHK(train_apply(net, t, lr));
   in.wbuf = net->hogwild ? -1 : t.wrote;
+  in.wbuf_seq = t.wrote_seq;
   HIPCHK(hipEventRecord(in.done, t.st));
   stat_add(net, GA3C_STAT_TRAIN_CALLS, 1);
   stat_add(net, GA3C_STAT_TRAIN_ROWS, B);
@@ -1102,7 +1113,7 @@ int train_enqueue(ga3c_net* net, TrainLane& t, Intake& in, int B, float lr, floa
 int train_finish(ga3c_net* net, Intake& in, float* losses) {
   const int64_t t0 = now_ns();
   HIPCHK(hipEventSynchronize(in.done));
-  adopt_buffer(net, in.wbuf);
+  adopt_buffer(net, in.wbuf, in.wbuf_seq);
   if (losses) memcpy(losses, in.losses, 3 * sizeof(float));
   stat_add(net, GA3C_STAT_TRAIN_SYNC_NS, now_ns() - t0);
   return GA3C_OK;
@@ -1660,6 +1671,7 @@ int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t
   }
   for (size_t i = 0; i < net->lanes.size(); ++i)
     if (net->lanes[i] == L) *ticket = (int32_t)i;
+  L->begun.store(true);
   return GA3C_OK;
 }
 
@@ -1668,6 +1680,7 @@ int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, fl
   if (ticket < 0 || ticket >= (int32_t)net->lanes.size()) return fail(GA3C_EINVAL, "bad ticket %d", ticket);
   if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
   Lane* L = net->lanes[(size_t)ticket];
+  if (!L->begun.exchange(false)) return fail(GA3C_ESTATE, "ticket %d: no batch was begun on that lane (or it was ended already)", ticket);
   const int64_t t0 = now_ns();
   const int rc = lane_wait(L);
   if (rc == GA3C_OK) {

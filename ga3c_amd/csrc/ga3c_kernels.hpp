@@ -44,7 +44,11 @@ __device__ unsigned long long* ga3c_stamp_buf = nullptr;     // [workgroup][16 w
 __device__ __forceinline__ void stamp_(int k) {
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t;
+#ifdef GA3C_STAMPS_REALTIME                                   // the 100 MHz counter all XCDs share (s_memtime is per XCD)
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+#else
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+#endif
   __builtin_amdgcn_sched_barrier(0);
   if ((threadIdx.x & 63) == 0 && ga3c_stamp_buf) ga3c_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + k] = t;
 }

@@ -147,7 +147,8 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
 /* ga3c_net_predict_gather in two halves, for a predictor loop that answers the previous batch while the GPU works on this
  * one (ga3c_pq_serve_pipelined, include/ga3c_host.h): begin takes a lane, stages the offsets and ENQUEUES the step; end
  * waits for it, copies p[batch, A] and v[batch] out and gives the lane back.  Every begin must be followed by its end, from
- * the same thread (the lane stays taken in between); a thread may have two begun. */
+ * the same thread (the lane stays taken in between); a thread may have two begun when the net has the lanes for it.  An end
+ * for a ticket on which nothing is begun returns GA3C_ESTATE. */
 int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket);
 int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, float* p, float* v);
 int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,

@@ -64,6 +64,16 @@ def test_gather_from_registered_transport_is_bit_identical_to_host_path():
         p1, v1 = net.predict_offsets(t.state_offsets(ids))
         p2, v2 = net.predict_p_and_v(frames[ids].reshape(-1, 84, 84, 4))
         assert np.array_equal(p1, p2) and np.array_equal(v1, v2)
+        # the split call of the pipelined predictor loop (begin: enqueue; end: wait + copy out): the same bits, and an end
+        # without a begin is refused instead of unlocking a lane nobody holds
+        import _native as nat
+        offs64 = np.ascontiguousarray(t.state_offsets(ids), dtype=np.int64)
+        ticket = nat.C.c_int32(-1)
+        nat.check(net._lib.ga3c_net_predict_gather_begin(net._h, nat.ptr(offs64, nat.i64p), ids.size, 1, nat.C.byref(ticket)), "begin")
+        p3, v3 = np.empty_like(p1), np.empty_like(v1)
+        nat.check(net._lib.ga3c_net_predict_gather_end(net._h, ticket.value, ids.size, nat.ptr(p3), nat.ptr(v3)), "end")
+        assert np.array_equal(p1, p3) and np.array_equal(v1, v3)
+        assert net._lib.ga3c_net_predict_gather_end(net._h, ticket.value, ids.size, nat.ptr(p3), nat.ptr(v3)) < 0
         # training rows out of two rollout slots
         offs, xs = [], []
         for slot, rows in ((3, 6), (5, 4)):
