@@ -266,6 +266,8 @@ struct ga3c_net {
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
                                        // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
+  int wd_step_in_conv_bwd = 1;         // fused update: dense1/w stepped inside conv_bwd (GA3C_WD_STEP_IN_CONV_BWD: 0 never -- in
+                                       // dense1_bwd_tile's epilogue --, 1 when conv_bwd's grid covers the 242 row groups, 2 always)
   bool d1_heads = false;               // GA3C_D1_HEADS=1: dense1 forward + heads in one launch, last-arriving workgroup of a row tile.
                                        // Measured: 29 us against 5.7 + 5.8 us as two launches (profiles/README.md) -- kept for the record, off
   int d1f_frag_lanes = 2;              // prediction steps of >= 64 rows use the register-fragment dense1 (no LDS: it shares a CU
@@ -447,6 +449,12 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   HeadBwdArgs hb;
   hb.B = B; hb.A = A; hb.d1 = t.f.d1; hb.dz = t.dz; hb.dv = t.dv; hb.lossrow = t.lossrow;
   hb.g_wp = g + OFF_WP; hb.g_bp = g + off_bp(A); hb.g_wv = g + OFF_WV; hb.g_bv = g + OFF_BV; hb.losses = t.losses;
+  // dense1/w stepped inside conv_bwd, beside its MFMA phases, instead of in dense1_bwd_tile's epilogue: worth 0.5 us of the
+  // 128-row step (the step's 24 MB cost conv_bwd 2.2 us where they cost the epilogue 3.5) while every workgroup of conv_bwd
+  // steps ONE 16-row group; below 121 rows the groups left over are a tail and it loses 0.2 us (profiles/README.md)
+  const bool fused_cb = net->conv_bwd_fused && B <= 128;
+  upd.defer_wd = upd.on && fused_cb && B <= net->d1b_tile_max &&
+                 (net->wd_step_in_conv_bwd >= 2 || (net->wd_step_in_conv_bwd == 1 && 2 * B >= KSTEPS_DENSE));
   if (B <= net->d1b_tile_max) {
     Dense1TileArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
@@ -469,16 +477,16 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     NCCLCHK(ncclAllReduce(g + OFF_WD, g + OFF_WD, (size_t)(net->n - OFF_WD), ncclFloat, ncclSum, net->comm, net->cst));
   }
   int nch1, nch2;
-  if (net->conv_bwd_fused && B <= 128) {   // one workgroup per CU: beyond one round the tail of the second costs more than the fusion saves
+  if (fused_cb) {   // one workgroup per CU: beyond one round the tail of the second costs more than the fusion saves
     // conv2_dw + conv2_dx + conv1_dw of a sample half in ONE workgroup (conv_bwd_kernel): dn1 never leaves the chip between them
     const int grid = 2 * B;                         // (sample, half); one slab pair per workgroup
     const size_t lds = CB_LDS_FLOATS * sizeof(float);
     if (t.f.x_u8)
       hipLaunchKernelGGL(conv_bwd_kernel<true>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.xu8, t.f.n1, t.dn2,
-                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B);
+                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B, g + OFF_WD, upd);
     else
       hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.x, t.f.n1, t.dn2,
-                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B);
+                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B, g + OFF_WD, upd);
     nch1 = nch2 = grid;
   } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
@@ -1312,6 +1320,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1F_FRAG_LANES")) net->d1f_frag_lanes = atoi(e);
   if (const char* e = getenv("GA3C_D1_HEADS")) net->d1_heads = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
   if (const char* e = getenv("GA3C_GATHER_BLOCKS")) net->gather_max_blocks = atoi(e) > 0 ? atoi(e) : 32;
   for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
@@ -2282,7 +2291,16 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       if (B > 128) return fail(GA3C_EINVAL, "conv_bwd runs up to 128 rows");
       hipExtLaunchKernelGGL(conv_bwd_kernel<false>, dim3(2 * B), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, t.f.n1, t.dn2, net->theta_pk[net->latest] + PK_W2DX, t.dn1, t.slab2,
-                            t.slab1, B);
+                            t.slab1, B, (const float*)nullptr, FusedUpd{});
+    } else if (k == "conv_bwd_wdstep") {
+      if (B > 128) return fail(GA3C_EINVAL, "conv_bwd runs up to 128 rows");
+      FusedUpd fu{};
+      const int l = net->latest;
+      fu.tin = net->theta[l]; fu.tout = net->theta[l]; fu.ms = net->ms; fu.mom = net->mom; fu.pk = net->theta_pk[l];
+      fu.lr = 0.f; fu.omr = 0.f; fu.mu = 0.f; fu.eps = net->cfg.rmsprop_epsilon; fu.on = 1; fu.defer_wd = 1;
+      hipExtLaunchKernelGGL(conv_bwd_kernel<false>, dim3(2 * B), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
+                            t.ev0, t.ev1, 0, (const void*)t.f.x, t.f.n1, t.dn2, net->theta_pk[l] + PK_W2DX, t.dn1, t.slab2,
+                            t.slab1, B, (const float*)(g + OFF_WD), fu);
     } else if (k == "dense1_bwd_tile") {
       Dense1TileArgs d;
       d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;

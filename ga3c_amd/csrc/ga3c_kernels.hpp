@@ -74,6 +74,8 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 struct FusedUpd {
   const float* tin; float* tout; float* ms; float* mom; float* pk;   // pk: packed copies (dense1/w, conv12/w) of tout
   float lr, omr, mu, eps; int on;
+  int defer_wd;   // dense1/w is NOT stepped by the kernel that completes its gradient (dense1_bwd_tile) but by the next one
+                  // (conv_bwd), beside that kernel's MFMA phases: see wd_step_load / wd_step_apply
 };
 __device__ __forceinline__ float fused_rmsprop(const FusedUpd& u, int64_t i, float g) {
   float m = u.ms[i];
@@ -1486,8 +1488,9 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   // NOW, with the staging loads, and arrive under the MFMAs -- fetched in the epilogue they were a memory round trip and a
   // half in front of 4 MB of stores (13.4 us with the update against 8.6 us bare)
   const int64_t uidx = (int64_t)(k0 + (threadIdx.x >> 6)) * HID + (threadIdx.x & 63) * 4;
+  const bool upd_wd = UPD && !a.upd.defer_wd;                  // (kernel-uniform) deferred: conv_bwd steps dense1/w
   f32x4 pre_ms = zero4(), pre_th = zero4();
-  if (UPD) {
+  if (upd_wd) {
     pre_ms = ld4(a.upd.ms + OFF_WD + uidx);
     pre_th = ld4(a.upd.tin + OFF_WD + uidx);
   }
@@ -1614,7 +1617,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     const int64_t idx = uidx;
     const f32x4 gv = ld4(gt + row * HID + c4);
     *reinterpret_cast<f32x4*>(a.g_wd + idx) = gv;
-    if (UPD) {
+    if (upd_wd) {
       const FusedUpd& u = a.upd;
       f32x4 m = pre_ms;
       const f32x4 th = pre_th;
@@ -1633,7 +1636,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
       *reinterpret_cast<f32x4*>(gt + row * HID + c4) = tn;       // for the fragment-ordered copy below
     }
   }
-  if (UPD) {
+  if (upd_wd) {
     __syncthreads();
     // the fragment-ordered copy dense1_fwd reads: rows 4 kq .. 4 kq + 3 of column n are 16 contiguous bytes there
     const int n = threadIdx.x & 255, kq = threadIdx.x >> 8;
@@ -1815,11 +1818,69 @@ __device__ __forceinline__ int cb_class_pixel(int h, int py, int px, int m) {
   return ya < 5 ? (((py ? 11 : 12) + 2 * ya) << 8) | (2 * (e % nx) + px) : -1;
 }
 
+// The optimizer step of dense1/w riding in conv_bwd (FusedUpd::defer_wd).  In dense1_bwd_tile's epilogue the step was 20 MB
+// of loads and stores that every workgroup issued at the same moment, behind the MFMA phase: 4.7 us of a 14.3-us kernel
+// with nothing to hide them under.  conv_bwd is bound by MFMA and LDS and leaves the vector-memory path idle after its
+// staging: each workgroup steps one 16-row group of dense1/w (242 groups, 16 KB each) -- operands requested after phase 1
+// (in flight during phase 2), arithmetic and stores in front of the barrier
+// before phase 3, where early waves wait for late ones anyway; the stores drain under phase 3, which reads only LDS.  Thread ->
+// (column n = tid % 256, row quad q = tid / 256): rows 16 s + 4 q .. + 3 of column n, which are ONE 16-byte piece of the
+// fragment-ordered copy (pack_wd_kernel); the row-major arrays move as 256-byte runs per wave instruction.  Same arithmetic,
+// element by element, as fused_rmsprop / rmsprop_one.
+// Stores that go THROUGH the XCD's L2 to memory as they are issued (device scope: sc1) instead of staying dirty in it until
+// the end-of-kernel write-back: a kernel's end waits for its L2s to drain, so bytes stored early and written through cost
+// the kernel nothing, bytes left dirty cost it their write-back whenever they were stored.
+#ifdef GA3C_STORE_THROUGH
+__device__ __forceinline__ void store_through(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_through4(float* p, f32x4 v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __hip_atomic_store(p + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+__device__ __forceinline__ void store_through(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_through4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+#endif
+struct WdStep { float g[4], m[4], t[4]; };
+__device__ __forceinline__ void wd_step_load(const FusedUpd& u, const float* __restrict__ g_wd, int s, WdStep& w) {
+  const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int64_t i0 = (int64_t)(16 * s + 4 * q) * HID + n;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w.g[j] = g_wd[i0 + j * HID];
+    w.m[j] = u.ms[OFF_WD + i0 + j * HID];
+    w.t[j] = u.tin[OFF_WD + i0 + j * HID];
+  }
+}
+__device__ __forceinline__ void wd_step_apply(const FusedUpd& u, int s, const WdStep& w) {
+  const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int64_t i0 = OFF_WD + (int64_t)(16 * s + 4 * q) * HID + n;
+  f32x4 tn;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float m = w.m[j];
+    m += (w.g[j] * w.g[j] - m) * u.omr;
+    store_through(u.ms + i0 + j * HID, m);
+    float step = (w.g[j] * u.lr) / sqrtf(u.eps + m);
+    if (u.mu != 0.f) {
+      step = u.mom[i0 + j * HID] * u.mu + step;
+      store_through(u.mom + i0 + j * HID, step);
+    }
+    tn[j] = w.t[j] - step;
+    store_through(u.tout + i0 + j * HID, tn[j]);
+  }
+  store_through4(u.pk + ((size_t)s * HID + n) * 16 + 4 * q, tn);
+}
+
+// g_wd / u: the gradient of dense1/w (complete since the previous launch) and the optimizer step to apply to it here
+// (u.on && u.defer_wd; otherwise neither is touched)
 template <bool U8>
 __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__ x, const float* __restrict__ n1,
                                                        const float* __restrict__ dn2, const float* __restrict__ w2pk,
                                                        float* __restrict__ dn1, float* __restrict__ slab2,
-                                                       float* __restrict__ slab1, int B) {
+                                                       float* __restrict__ slab1, int B, const float* __restrict__ g_wd,
+                                                       FusedUpd u) {
   extern __shared__ __attribute__((aligned(16))) float cb_lds[];
   GA3C_STAMP(0);
   float* n1img = cb_lds;                                     // [14][24][16]  n1 rows n1org .. n1org+13, cols -1..22
@@ -1830,6 +1891,9 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   int* ptab = reinterpret_cast<int*>(xb + CB_XIMG);          // [4 classes][64 slots]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   if ((int)blockIdx.x >= 2 * B) return;                      // block-uniform
+  const bool step_wd = u.on && u.defer_wd;                   // kernel-uniform
+  const bool step_mine = step_wd && (int)blockIdx.x < KSTEPS_DENSE;
+  WdStep wst;
   int grp, h;
   cs_sample_half(blockIdx.x, B, grp, h);                     // both halves of a sample on one XCD (see cs_sample_half)
   const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;   // conv2 pixels of this half
@@ -1929,6 +1993,10 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       }
     }
     GA3C_STAMP(3);
+    // Requested HERE: phase 1 ends in a vmcnt(0) (its LDS reads may alias the x DMA as far as the compiler knows), so
+    // anything requested earlier is waited for there -- with the staging loads the step delayed the first barrier, with
+    // the x rows the end of phase 1, by the 2.4 us its 12 MB take (conv_bwd 17.4 -> 20.3 us both times).
+    if (step_mine) wd_step_load(u, g_wd, blockIdx.x, wst);
     // ---- phase 2: dW2 partial over conv2 pixels q0 .. q0+c2npix-1 (slots to 64 carry dn2 = 0)
     // wave = (patch row u, column half nh, K half kh: pixel slots 32 kh .. 32 kh + 31).  The 64 rows of dW2 that belong to
     // patch row u -- positions (u, 0..3) x 16 channels -- are 64 CONTIGUOUS floats of the n1 image at every conv2 pixel, so
@@ -1961,6 +2029,7 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       }
     }
     GA3C_STAMP(4);
+    if (step_mine) wd_step_apply(u, blockIdx.x, wst);        // early waves' arithmetic under the late waves' MFMAs; the stores drain under phase 3
     __syncthreads();                                         // dn1 of the half is complete in LDS; its x rows have landed
     GA3C_STAMP(5);
     // ---- phase 3: dW1 partial, band by band (no barrier between bands: the whole x image is resident);
@@ -2060,6 +2129,11 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
       }
     }
   }
+  if (step_wd)                                               // grids below 242 workgroups (B < 121): the groups left over
+    for (int s = blockIdx.x + gridDim.x; s < KSTEPS_DENSE; s += gridDim.x) {
+      wd_step_load(u, g_wd, s, wst);
+      wd_step_apply(u, s, wst);
+    }
   GA3C_STAMP(7);
 }
 

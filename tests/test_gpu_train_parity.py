@@ -117,6 +117,59 @@ def test_u8_and_f32_production_steps_give_the_same_bits(nets, bsz):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_dense1_weight_step_inside_conv_bwd_gives_the_bits_of_the_epilogue_step(nets, monkeypatch):
+    """The fused update steps dense1/w inside conv_bwd (beside its MFMA phases) instead of in dense1_bwd_tile's epilogue
+    (GA3C_WD_STEP_IN_CONV_BWD=0 keeps the epilogue, 2 defers at every batch size, the default from 121 rows on).  Same arithmetic per element: weights, ms and -- through the
+    fragment-ordered copy of dense1/w that predictions read -- the predictions after the steps must be bit-identical, at a
+    full grid (128 rows: one 16-row group per workgroup), at grids below the 242 groups (8, 40, 120 rows: the leftover
+    loop) and with momentum."""
+    import ga3c_amd  # noqa: F401
+    import Config
+    from NetworkVP import Network
+    monkeypatch.setenv("GA3C_WD_STEP_IN_CONV_BWD", "2")
+    ref = Network("gpu:0", "wd_conv_bwd", 6, (84, 84, 4), max_batch=136, predict_lanes=1)
+    monkeypatch.setenv("GA3C_WD_STEP_IN_CONV_BWD", "0")
+    net = Network("gpu:0", "wd_epilogue", 6, (84, 84, 4), max_batch=136, predict_lanes=1)
+    monkeypatch.delenv("GA3C_WD_STEP_IN_CONV_BWD")
+    dflt = nets(6)
+    try:
+        for bsz in (8, 40, 120, 121, 128):
+            xk, x, a, y = _batch(bsz, 6, 9100 + bsz)
+            outs = []
+            for n in (ref, net, dflt):
+                _reset(n, 6)
+                for xin in (x, xk, x):
+                    n.train(xin, y, a)
+                outs.append((n.get_arena(0), n.get_arena(1), n.predict_p_v_logits(x)))
+            for other in outs[1:]:
+                assert np.array_equal(outs[0][0], other[0]) and np.array_equal(outs[0][1], other[1]), bsz
+                assert all(np.array_equal(g, w) for g, w in zip(outs[0][2], other[2])), bsz
+            assert not np.array_equal(outs[0][0], _flat(o.init_params(6)).astype(np.float32))
+    finally:
+        net.close()
+        ref.close()
+    # momentum: a Network reads the optimizer's constants from Config when it is created
+    monkeypatch.setattr(Config.Config, "RMSPROP_MOMENTUM", 0.5)
+    pair = []
+    for flag in ("2", "0"):
+        monkeypatch.setenv("GA3C_WD_STEP_IN_CONV_BWD", flag)
+        pair.append(Network("gpu:0", "wd_mom" + flag, 6, (84, 84, 4), max_batch=136, predict_lanes=1))
+    monkeypatch.delenv("GA3C_WD_STEP_IN_CONV_BWD")
+    try:
+        xk, x, a, y = _batch(64, 6, 9164)
+        outs = []
+        for n in pair:
+            _reset(n, 6)
+            for _ in range(3):
+                n.train(x, y, a)
+            outs.append((n.get_arena(0), n.get_arena(1), n.get_arena(2)))
+        assert all(np.array_equal(g, w) for g, w in zip(outs[0], outs[1]))
+        assert np.any(outs[0][2] != 0)
+    finally:
+        for n in pair:
+            n.close()
+
+
 @pytest.mark.parametrize("num_actions", [6, 18])
 def test_train_offsets_on_132_transport_rows_matches_oracle(num_actions):
     """The zero-copy trainer path at the engine's own batch: 132 rows lying in 22 rollout slots of the registered

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
                        pk + PK_W2F, th + OFF_B2, n1, n2, B, (const int64_t*)nullptr); };
   auto bwd = [&](hipStream_t s) {
     hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(B * 2), dim3(1024), lds_b, s, (const void*)x, n1, dn2, pk + PK_W2DX, (float*)nullptr,
-                       slab2, slab1, B); };
+                       slab2, slab1, B, (const float*)nullptr, FusedUpd{}); };
   hipEvent_t e0; CK(hipEventCreate(&e0));
   unsigned long long *sb, *tt;                              // main kernel's stamps [wg][16 waves][16], proxies' [chain][wg][2]
   CK(hipMalloc(&sb, (size_t)256 * 16 * 16 * 8)); CK(hipMalloc(&tt, (size_t)8 * 4096 * 2 * 8));

@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
     const int grid = 2 * B;
     for (int it = 0; it < 4; ++it) {
       CK(hipMemsetAsync(sb, 0, (size_t)nwg * 16 * 16 * 8, st));
-      hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), cl, st, (const void*)x, n1, dn2, pk, dn1, slab2, slab1, B);
+      hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), cl, st, (const void*)x, n1, dn2, pk, dn1, slab2, slab1, B, (const float*)nullptr, FusedUpd{});
       CK(hipStreamSynchronize(st));
     }
     std::vector<unsigned long long> h((size_t)nwg * 16 * 16);
