@@ -89,6 +89,7 @@ struct Fwd {   // forward workspace of one lane (device pointers)
   // prediction intake fused into the conv stack: sample b lies src_off[b] bytes behind src_base (nullptr: dense batch)
   const uint8_t* src_base = nullptr;
   const int64_t* src_off = nullptr;
+  const int64_t* src_off_host = nullptr;   // the same array as the host sees it (pinned: same address; kept apart for clarity)
 };
 
 struct Lane {
@@ -266,6 +267,8 @@ struct ga3c_net {
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
                                        // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
+  bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
+  bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
   int wd_step_in_conv_bwd = 1;         // fused update: dense1/w stepped inside conv_bwd (GA3C_WD_STEP_IN_CONV_BWD: 0 never -- in
                                        // dense1_bwd_tile's epilogue --, 1 when conv_bwd's grid covers the 242 row groups, 2 always)
   bool d1_heads = false;               // GA3C_D1_HEADS=1: dense1 forward + heads in one launch, last-arriving workgroup of a row tile.
@@ -396,9 +399,15 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (f.src_off && !(net->fused_conv && B <= FUSED_CONV_MAX_B)) return fail(GA3C_ESTATE, "scattered intake needs the fused conv stack");
   if (net->fused_conv && B <= FUSED_CONV_MAX_B) {   // one workgroup per CU: pays off only while a batch is a single wave of workgroups
     const size_t lds = CS_LDS_FLOATS * sizeof(float);
+    SrcOffsets so;
+    so.n = 0;
+    if (f.src_off && f.src_off_host && !net->graphs && net->offsets_in_args) {   // plain launch: the offsets ride in the kernel arguments
+      memcpy(so.off, f.src_off_host, (size_t)B * sizeof(int64_t));
+      so.n = B;
+    }
 #define CSTACK(T, U)                                                                                                \
   hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, net->theta_pk[idx] + PK_W1F, th + OFF_B1, \
-                     net->theta_pk[idx] + PK_W2F, th + OFF_B2, f.n1, f.n2, B, f.src_off)
+                     net->theta_pk[idx] + PK_W2F, th + OFF_B2, f.n1, f.n2, B, f.src_off, so)
     if (train) { if (f.x_u8) CSTACK(true, true); else CSTACK(true, false); }
     else { if (f.x_u8) CSTACK(false, true); else CSTACK(false, false); }
 #undef CSTACK
@@ -554,15 +563,19 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
       // small batches (every engine batch): the conv stack reads the scattered states itself -- one launch less
       L.f.src_base = base;
       L.f.src_off = L.h_off;
+      L.f.src_off_host = L.h_off;
     } else {
       const SmallCopy none{nullptr, nullptr, 0, nullptr, nullptr, 0};
-      if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.xu8), B, none);
-      else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B, none);
+      RowOffsets ro;
+      ro.n = 0;                                              // (beyond the fused conv stack's range: batches of more than 128 rows)
+      if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.xu8), B, none, ro);
+      else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B, none, ro);
     }
   }
   const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
   L.f.src_base = nullptr;
   L.f.src_off = nullptr;
+  L.f.src_off_host = nullptr;
   return rc;
 }
 
@@ -627,7 +640,9 @@ int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* o
     CHK(adopt_finished(net));
   }
   const int idx = net->cur.load();      // a finished step's weights: nothing to wait for
+  if (net->time_predictions) HIPCHK(hipEventRecord(L.tm0, L.st));
   CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
+  if (net->time_predictions) HIPCHK(hipEventRecord(L.tm1, L.st));
   HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
   return GA3C_OK;
@@ -849,10 +864,16 @@ int launch_gather(ga3c_net* net, const int64_t* offsets, int B, bool u8, Stage& 
     memcpy(ha, a, (size_t)B * net->A * sizeof(float));
     sc.src1 = ha; sc.dst1 = s.act; sc.n1 = B * net->A;
   }
+  RowOffsets ro;
+  ro.n = 0;
+  if (B <= 192 && net->offsets_in_args) {                    // the engine's train batches: offsets in the kernel arguments
+    memcpy(ro.off, s.h_off, (size_t)B * sizeof(int64_t));
+    ro.n = B;
+  }
   if (u8) {
-    hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.xu8), B, sc);
+    hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.xu8), B, sc, ro);
   } else {
-    hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.x), B, sc);
+    hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, s.st, net->reg_dev, s.h_off, reinterpret_cast<uint4*>(s.x), B, sc, ro);
   }
   s.x_u8 = u8;
   HIPCHK(hipGetLastError());
@@ -964,6 +985,12 @@ struct LaneGuard {
   LaneGuard& operator=(const LaneGuard&) = delete;
 };
 
+// after lane_wait: the GPU span of the step lane_forward enqueued (diagnostic switch)
+void note_predict_span(ga3c_net* net, Lane* L) {
+  float ms = 0.f;
+  if (net->time_predictions && hipEventElapsedTime(&ms, L->tm0, L->tm1) == hipSuccess) stat_add(net, GA3C_STAT_PREDICT_GPU_NS, (int64_t)(ms * 1e6f));
+}
+
 // wait until everything lane L has enqueued is done (L's mutex is held)
 int lane_wait(Lane* L) {
   if (!L->shared_st) {
@@ -987,6 +1014,7 @@ int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, 
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
   const int64_t t1 = now_ns();
   CHK(lane_wait(L));
+  note_predict_span(net, L);
   stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
   stat_add(net, GA3C_STAT_PREDICT_ROWS, B);
   stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
@@ -1321,6 +1349,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1_HEADS")) net->d1_heads = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
+  if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
   if (const char* e = getenv("GA3C_GATHER_BLOCKS")) net->gather_max_blocks = atoi(e) > 0 ? atoi(e) : 32;
   for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
@@ -1672,6 +1702,9 @@ int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t
     float* hp = L->h_out;
     float* hv = hp + (size_t)net->maxB * net->A;
     rc = lane_forward(net, *L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, hp, hv);
+    // the completion event goes in right behind the step, not when _end comes to wait: recorded there it was a round trip
+    // through the queue of its own, after a step that had long finished
+    if (rc == GA3C_OK && hipEventRecord(L->done, L->st) != hipSuccess) rc = fail(GA3C_EHIP, "hipEventRecord failed");
     stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, now_ns() - t0);
   }
   if (rc != GA3C_OK) {
@@ -1691,8 +1724,10 @@ int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, fl
   Lane* L = net->lanes[(size_t)ticket];
   if (!L->begun.exchange(false)) return fail(GA3C_ESTATE, "ticket %d: no batch was begun on that lane (or it was ended already)", ticket);
   const int64_t t0 = now_ns();
-  const int rc = lane_wait(L);
+  const hipError_t he = hipEventSynchronize(L->done);      // recorded by _begin, behind the step
+  const int rc = he == hipSuccess ? GA3C_OK : fail(GA3C_EHIP, "hipEventSynchronize failed: %s", hipGetErrorString(he));
   if (rc == GA3C_OK) {
+    note_predict_span(net, L);
     const float* hp = L->h_out;
     const float* hv = hp + (size_t)net->maxB * net->A;
     memcpy(p, hp, (size_t)batch * net->A * sizeof(float));
@@ -1932,6 +1967,7 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
   const int64_t t1 = now_ns();
   CHK(lane_wait(L));
+  note_predict_span(net, L);
   stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
   stat_add(net, GA3C_STAT_PREDICT_ROWS, want);
   stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
@@ -2241,15 +2277,15 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "conv_stack_fwd") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
-                            (const int64_t*)nullptr);
+                            (const int64_t*)nullptr, SrcOffsets{});
     } else if (k == "conv_stack_fwd_train") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<true, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
-                            (const int64_t*)nullptr);
+                            (const int64_t*)nullptr, SrcOffsets{});
     } else if (k == "conv_stack_fwd_u8") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.xu8, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
-                            (const int64_t*)nullptr);
+                            (const int64_t*)nullptr, SrcOffsets{});
     } else if (k == "dense1_fwd" || k == "dense1_fwd_frag") {
       const bool keep = net->d1f_tile;
       if (k == "dense1_fwd_frag") net->d1f_tile = false;

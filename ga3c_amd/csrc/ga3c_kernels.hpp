@@ -153,10 +153,14 @@ inline int gather_blocks(int B, int chunks, int max_blocks) {
 // copied by the last workgroup, so that staging a batch is ONE launch instead of a gather and two copy kernels
 struct SmallCopy { const float* src0; float* dst0; int n0; const float* src1; float* dst1; int n1; };
 
+// ... and the rows' offsets travelling with the launch (n > 0) instead of being read out of the pinned array: every work
+// item's data loads waited for a scalar load over PCIe in front of them -- a round trip per trip of the loop
+struct RowOffsets { int64_t off[192]; int n; };
+
 template <int CHUNKS>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ host_base,
                                                           const int64_t* __restrict__ offsets, uint4* __restrict__ dst, int B,
-                                                          SmallCopy sc) {
+                                                          SmallCopy sc, const RowOffsets ro) {
   constexpr int PIECES = (CHUNKS + 255) / 256;
   const int items = B * PIECES;
   const int tid = threadIdx.x;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restr
       const int it = it0 + u;
       const int b = it / PIECES, c = (it - b * PIECES) * 256 + tid;
       live[u] = it < items && c < CHUNKS;
-      if (live[u]) v[u] = *reinterpret_cast<const uint4*>(host_base + offsets[b] + (size_t)c * 16);
+      if (live[u]) v[u] = *reinterpret_cast<const uint4*>(host_base + (ro.n ? ro.off[b < 192 ? b : 0] : offsets[b]) + (size_t)c * 16);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -385,13 +389,18 @@ __device__ __forceinline__ void cs_n1_pixel(int h, int m, int& row, int& col) {
   }
 }
 
+// The byte offsets of a scattered batch travelling with the launch (kernel arguments live in device memory: a scalar load
+// out of HBM) instead of being read out of the pinned host array the caller filled -- that read was a PCIe round trip of its
+// own in front of the staging loads that depend on it.  n = 0: read src_off (hipGraph replays: arguments are baked in).
+struct SrcOffsets { int64_t off[128]; int n; };
+
 // w1f / w2f: the filter banks in forward fragment order (theta_pk + PK_W1F / PK_W2F)
 template <bool TRAIN, bool U8>
 __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w1f,
                                                              const float* __restrict__ b1, const float* __restrict__ w2f,
                                                              const float* __restrict__ b2, float* __restrict__ n1,
                                                              float* __restrict__ n2, int B,
-                                                             const int64_t* __restrict__ src_off) {
+                                                             const int64_t* __restrict__ src_off, const SrcOffsets so) {
   extern __shared__ __attribute__((aligned(16))) float cs_lds[];
   float* img = cs_lds;
   float* n1l = cs_lds + CS_X_FLOATS;
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
   cs_sample_half(blockIdx.x, B, b, h);
   // src_off: the states are not a dense batch but lie src_off[b] bytes behind x (transport slots in registered host
   // memory, or the device-side frame queues): the intake gather happens here, in the staging loads
-  const void* xs = src_off ? static_cast<const void*>(static_cast<const char*>(x) + src_off[b]) : x;
+  const void* xs = src_off ? static_cast<const void*>(static_cast<const char*>(x) + (so.n ? so.off[b] : src_off[b])) : x;
   const size_t sb = src_off ? 0 : (size_t)b;
   const int q0 = h ? CS_C2CUT : 0, c2npix = h ? P2 - CS_C2CUT : CS_C2CUT;     // conv2 pixels of this half
   const int c2r0 = h ? 5 : 0;                                // first conv2 row it touches

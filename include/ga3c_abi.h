@@ -223,6 +223,8 @@ enum {
   GA3C_STAT_TRAIN_LAUNCH_NS,       /* host time to enqueue forward + backward + update */
   GA3C_STAT_TRAIN_SYNC_NS,         /* from the last launch to the step's completion */
   GA3C_STAT_TRAIN_READER_WAITS,    /* cross-stream waits a step issued for prediction lanes still reading the buffer it overwrites */
+  GA3C_STAT_PREDICT_GPU_NS,        /* GPU span of a prediction step, first kernel's start to last kernel's end; collected only with
+                                      GA3C_TIME_PREDICTIONS=1 in the environment (two timing events per step) */
   GA3C_STAT_COUNT
 };
 int ga3c_net_stats(ga3c_net* net, int64_t* out, int32_t n, int32_t reset);

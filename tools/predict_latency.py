@@ -21,15 +21,19 @@ for n in (1, 8, 16, 32, 64, 128):
     x = np.ascontiguousarray(t.agent_states[:n]).reshape(n, 84, 84, 4)
     for _ in range(50):
         net.predict_offsets(offs)
+    net.stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(500):
         net.predict_offsets(offs)
     a = (time.perf_counter() - t0) / 500 * 1e6
+    st = net.stats(reset=True)
+    c = max(st["predict_calls"], 1)
+    split = "launch %.1f sync %.1f gpu span %.1f" % (st["predict_launch_ns"] / c / 1e3, st["predict_sync_ns"] / c / 1e3, st["predict_gpu_ns"] / c / 1e3)
     for _ in range(50):
         net.predict_p_and_v(x)
     t0 = time.perf_counter()
     for _ in range(500):
         net.predict_p_and_v(x)
     b = (time.perf_counter() - t0) / 500 * 1e6
-    print("batch %3d: zero-copy gather %.1f us per call, host-buffer u8 %.1f us per call" % (n, a, b))
+    print("batch %3d: zero-copy gather %.1f us per call (%s; the span only with GA3C_TIME_PREDICTIONS=1), host-buffer u8 %.1f us per call" % (n, a, split, b))
 net.unregister_transport(); net.close(); t.shutdown(); t.close()
