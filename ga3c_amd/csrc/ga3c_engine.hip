@@ -470,8 +470,9 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     d.hb = hb;
     d.upd = upd;
     d.role_blocks = A + 2 < 14 ? A + 2 : 14;       // 242 tiles + the roles stay within one round of workgroups on 256 CUs
-    if (upd.on) hipLaunchKernelGGL(dense1_bwd_tile_kernel<true>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
-    else hipLaunchKernelGGL(dense1_bwd_tile_kernel<false>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+    if (upd.on && upd.defer_wd) hipLaunchKernelGGL(dense1_bwd_tile_kernel<2>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+    else if (upd.on) hipLaunchKernelGGL(dense1_bwd_tile_kernel<1>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+    else hipLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
   } else {
     Dense1BwdArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
@@ -490,12 +491,13 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     // conv2_dw + conv2_dx + conv1_dw of a sample half in ONE workgroup (conv_bwd_kernel): dn1 never leaves the chip between them
     const int grid = 2 * B;                         // (sample, half); one slab pair per workgroup
     const size_t lds = CB_LDS_FLOATS * sizeof(float);
-    if (t.f.x_u8)
-      hipLaunchKernelGGL(conv_bwd_kernel<true>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.xu8, t.f.n1, t.dn2,
-                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B, g + OFF_WD, upd);
-    else
-      hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(grid), dim3(1024), lds, st, (const void*)t.f.x, t.f.n1, t.dn2,
-                         net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B, g + OFF_WD, upd);
+#define CONV_BWD(U, W, XP)                                                                                                  \
+  hipLaunchKernelGGL((conv_bwd_kernel<U, W>), dim3(grid), dim3(1024), lds, st, (const void*)(XP), t.f.n1, t.dn2,              \
+                     net->theta_pk[idx] + PK_W2DX, keep_dn1 ? t.dn1 : nullptr, t.slab2, t.slab1, B, g + OFF_WD, upd)
+    const bool wd = upd.on && upd.defer_wd;
+    if (t.f.x_u8) { if (wd) CONV_BWD(true, true, t.f.xu8); else CONV_BWD(true, false, t.f.xu8); }
+    else { if (wd) CONV_BWD(false, true, t.f.x); else CONV_BWD(false, false, t.f.x); }
+#undef CONV_BWD
     nch1 = nch2 = grid;
   } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
@@ -1353,7 +1355,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
   if (const char* e = getenv("GA3C_GATHER_BLOCKS")) net->gather_max_blocks = atoi(e) > 0 ? atoi(e) : 32;
-  for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false>)}) {
+  for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true, false>), reinterpret_cast<const void*>(&conv_bwd_kernel<false, false>),
+                         reinterpret_cast<const void*>(&conv_bwd_kernel<true, true>), reinterpret_cast<const void*>(&conv_bwd_kernel<false, true>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CB_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) {
       delete net;
@@ -1370,7 +1373,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
       return fail(GA3C_EHIP, "cannot reserve LDS for dense1_fwd_tile_kernel: %s", hipGetErrorString(e));
     }
   }
-  for (const void* fn : {reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<true>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<false>)}) {
+  for (const void* fn : {reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<0>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<1>),
+                         reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<2>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) {
       delete net;
@@ -2334,7 +2338,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       const int l = net->latest;
       fu.tin = net->theta[l]; fu.tout = net->theta[l]; fu.ms = net->ms; fu.mom = net->mom; fu.pk = net->theta_pk[l];
       fu.lr = 0.f; fu.omr = 0.f; fu.mu = 0.f; fu.eps = net->cfg.rmsprop_epsilon; fu.on = 1; fu.defer_wd = 1;
-      hipExtLaunchKernelGGL(conv_bwd_kernel<false>, dim3(2 * B), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
+      hipExtLaunchKernelGGL((conv_bwd_kernel<false, true>), dim3(2 * B), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, t.f.n1, t.dn2, net->theta_pk[l] + PK_W2DX, t.dn1, t.slab2,
                             t.slab1, B, (const float*)(g + OFF_WD), fu);
     } else if (k == "dense1_bwd_tile") {
@@ -2344,7 +2348,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
       d.role_blocks = net->A + 2 < 14 ? net->A + 2 : 14;
       memset(&d.upd, 0, sizeof d.upd);
-      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<false>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
+      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, d);
     } else if (k == "heads") {
       HeadArgs h;

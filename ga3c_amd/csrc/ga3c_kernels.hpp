@@ -1470,14 +1470,15 @@ struct Dense1TileArgs {
   FusedUpd upd;      // on: dense1/w, dense1/b and the head parameters are stepped here (see FusedUpd)
 };
 
-// UPD: the launch also steps the parameters whose gradients it completes (FusedUpd; a.upd.on says the same at run time).
-// A template argument rather than a run-time switch so that the two forms are two kernels to a profiler: their HBM
-// traffic differs by the optimizer's 16 MB (profiles/: tools/pmc_table.py lists them as separate rows).
-template <bool UPD>
+// UPD: the launch also steps the parameters whose gradients it completes (FusedUpd; a.upd.on says the same at run time):
+// 1 all of them, 2 all but dense1/w (FusedUpd::defer_wd: the next launch, conv_bwd, steps it).  A template argument rather
+// than a run-time switch so that the forms are separate kernels to a profiler: their HBM traffic differs by the optimizer's
+// 16 MB (profiles/: tools/pmc_table.py lists them as separate rows).
+template <int UPD>
 __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float d1b_lds[];
   if ((int)blockIdx.x >= D1B_TILES) {                       // block-uniform: the head roles, dealt round-robin
-    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide<UPD>(a.hb, role, d1b_lds, a.upd);
+    for (int role = blockIdx.x - D1B_TILES; role < a.hb.A + 2; role += a.role_blocks) heads_bwd_role_wide<(UPD != 0)>(a.hb, role, d1b_lds, a.upd);
     return;
   }
   float* dds = d1b_lds;                                     // [128][260]  dd1 rows of the chunk
@@ -1497,7 +1498,7 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   // NOW, with the staging loads, and arrive under the MFMAs -- fetched in the epilogue they were a memory round trip and a
   // half in front of 4 MB of stores (13.4 us with the update against 8.6 us bare)
   const int64_t uidx = (int64_t)(k0 + (threadIdx.x >> 6)) * HID + (threadIdx.x & 63) * 4;
-  const bool upd_wd = UPD && !a.upd.defer_wd;                  // (kernel-uniform) deferred: conv_bwd steps dense1/w
+  constexpr bool upd_wd = UPD == 1;
   f32x4 pre_ms = zero4(), pre_th = zero4();
   if (upd_wd) {
     pre_ms = ld4(a.upd.ms + OFF_WD + uidx);
@@ -1882,9 +1883,10 @@ __device__ __forceinline__ void wd_step_apply(const FusedUpd& u, int s, const Wd
   store_through4(u.pk + ((size_t)s * HID + n) * 16 + 4 * q, tn);
 }
 
-// g_wd / u: the gradient of dense1/w (complete since the previous launch) and the optimizer step to apply to it here
-// (u.on && u.defer_wd; otherwise neither is touched)
-template <bool U8>
+// WD: the launch also applies the optimizer step u to dense1/w, whose gradient g_wd is complete since the previous launch
+// (FusedUpd::defer_wd; a template argument so that a profiler lists the two forms apart: their traffic differs by 24 MB);
+// otherwise neither g_wd nor u is touched
+template <bool U8, bool WD = false>
 __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__ x, const float* __restrict__ n1,
                                                        const float* __restrict__ dn2, const float* __restrict__ w2pk,
                                                        float* __restrict__ dn1, float* __restrict__ slab2,
@@ -1900,7 +1902,7 @@ __global__ __launch_bounds__(1024) void conv_bwd_kernel(const void* __restrict__
   int* ptab = reinterpret_cast<int*>(xb + CB_XIMG);          // [4 classes][64 slots]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
   if ((int)blockIdx.x >= 2 * B) return;                      // block-uniform
-  const bool step_wd = u.on && u.defer_wd;                   // kernel-uniform
+  constexpr bool step_wd = WD;
   const bool step_mine = step_wd && (int)blockIdx.x < KSTEPS_DENSE;
   WdStep wst;
   int grp, h;

@@ -49,14 +49,18 @@ ALGORITHMIC_MB = {
     "conv1_fwd_kernel<false>": X_F32 + N1, "conv2_fwd_kernel": N1 + N2,
     "dense1_fwd_tile_kernel<1>": N2 + WD + PART, "dense1_fwd_kernel<1>": N2 + WD + PART,
     "heads_kernel<false, 8>": PART + 0.14, "heads_kernel<true, 8>": PART + 0.28,
-    # <false>: gradients only; <true>: + the optimizer step of dense1/w in the epilogue (ms read + written, weights written,
-    # packed copy written: 4 x 3.96 MB; the weights themselves are read for the dn2 product either way)
-    "dense1_bwd_tile_kernel<false>": N2 + 0.13 + WD + WD + N2, "dense1_bwd_tile_kernel<true>": N2 + 0.13 + WD + WD + N2 + 4 * WD,
+    # (the step of dense1/w: ms read + written, weights written, packed copy written: 4 x 3.96 MB in the epilogue, where the
+    # gradient is on chip and the weights are read for the dn2 product anyway; 6 x in conv_bwd, which reads both)
+    # <0>: gradients only; <1>: + the optimizer step of dense1/w in the epilogue; <2>: the step of the small parameters only
+    # (dense1/w is stepped by the next launch, conv_bwd<.., true>: gradient, ms and weights read, ms, weights and packed copy written)
+    "dense1_bwd_tile_kernel<0>": N2 + 0.13 + WD + WD + N2, "dense1_bwd_tile_kernel<1>": N2 + 0.13 + WD + WD + N2 + 4 * WD,
+    "dense1_bwd_tile_kernel<2>": N2 + 0.13 + WD + WD + N2,
     "dense1_bwd_kernel": N2 + 0.13 + WD + WD + N2,
     "dense1_dw_kernel": N2 + 0.13 + WD, "dense1_dx_kernel": 0.13 + WD + N2 + N2,
     "conv2_dw_kernel": N1 + N2 + 128 * 8224 * 4 / MB, "conv2_dx_kernel": N2 + N1 + N1,
     "conv1_dw_kernel<false>": X_F32 + N1 + 256 * 4112 * 4 / MB, "conv1_dw_kernel<true>": X_U8 + N1 + 256 * 4112 * 4 / MB,
-    "conv_bwd_kernel<false>": X_F32 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB, "conv_bwd_kernel<true>": X_U8 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB,
+    "conv_bwd_kernel<false, false>": X_F32 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB, "conv_bwd_kernel<true, false>": X_U8 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB,
+    "conv_bwd_kernel<false, true>": X_F32 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB + 6 * WD, "conv_bwd_kernel<true, true>": X_U8 + N1 + N2 + 256 * (4112 + 8224) * 4 / MB + 6 * WD,
     # slabs read once: train steps reduce the 256 slab pairs of conv_bwd (256 x (4112 + 8224) floats), the per-kernel timer
     # the 512 + 128 slabs of the split kernels -- 12.63 MB either way
     "slab_reduce_kernel<false>": 256 * (4112 + 8224) * 4 / MB,
