@@ -105,8 +105,7 @@ struct Lane {
   float* h_in = nullptr;    // pinned staging, max_batch states
   float* h_out = nullptr;   // pinned staging, p|v|z
   int64_t* h_off = nullptr; // pinned: per-row byte offsets, read in place by the gather kernels
-  hipEvent_t read_done[3] = {nullptr, nullptr, nullptr};
-  bool dirty[3] = {false, false, false};   // read_done[i] recorded since theta[i] was last written (guarded by wmu)
+  bool dirty[3] = {false, false, false};   // a step of this lane has read theta[i] since it was last written (guarded by wmu); `done` is behind it
   // captured prediction steps, one executable graph per (batch, weight buffer, intake mode, output target): every
   // pointer a step touches is fixed for the lane's lifetime, so a step is replayed with ONE launch call
   std::unordered_map<int64_t, hipGraphExec_t> graphs;
@@ -267,6 +266,7 @@ struct ga3c_net {
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
                                        // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
+  bool stop_events = true;             // GA3C_STOP_EVENTS=0: a prediction step's completion event is a hipEventRecord of its own
   bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
   bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
   int wd_step_in_conv_bwd = 1;         // fused update: dense1/w stepped inside conv_bwd (GA3C_WD_STEP_IN_CONV_BWD: 0 never -- in
@@ -390,8 +390,10 @@ int launch_dense1_heads(ga3c_net* net, const Fwd& f, const float* pk, const Head
 
 constexpr int HEADS_WAVES = 1;   // samples (waves) per heads workgroup
 // ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
+// stop_ev: recorded behind the step -- as the completion event of its LAST launch (hipExtLaunchKernelGGL), which saves the
+// host the hipEventRecord call and the queue a packet of its own
 int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, bool train,
-                   const TrainLane* tl, float beta, float* out_p = nullptr, float* out_v = nullptr) {
+                   const TrainLane* tl, float beta, float* out_p = nullptr, float* out_v = nullptr, hipEvent_t stop_ev = nullptr) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   const int A = net->A;
   const float* th = net->theta[idx];
@@ -429,13 +431,18 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   if (train) { h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.dd1 = tl->dd1; h.beta = beta; }
   if (dense1_heads_fits(net, B, ks)) {
     CHK(launch_dense1_heads(net, f, net->theta_pk[idx], h, B, ks, st, train, nullptr, nullptr));
+    if (stop_ev) HIPCHK(hipEventRecord(stop_ev, st));
     return GA3C_OK;
   }
   // several prediction lanes at work: the fragment kernel (no LDS) runs beside the other lanes' conv stacks
   const bool frag = !train && !net->graphs && net->d1f_frag_lanes > 0 && B >= 64 &&
                     net->predict_inflight.load(std::memory_order_relaxed) >= net->d1f_frag_lanes;
   CHK(launch_dense1_fwd(net, f.n2, net->theta_pk[idx], f.part, B, ks, st, nullptr, nullptr, frag));
-#define HEADS(T, AM) hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + HEADS_WAVES - 1) / HEADS_WAVES), dim3(64 * HEADS_WAVES), 0, st, h)
+#define HEADS(T, AM)                                                                                                        \
+  do {                                                                                                                      \
+    if (stop_ev) hipExtLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + HEADS_WAVES - 1) / HEADS_WAVES), dim3(64 * HEADS_WAVES), 0, st, nullptr, stop_ev, 0, h); \
+    else hipLaunchKernelGGL((heads_kernel<T, AM>), dim3((B + HEADS_WAVES - 1) / HEADS_WAVES), dim3(64 * HEADS_WAVES), 0, st, h);                                 \
+  } while (0)
   if (A <= 8) { if (train) HEADS(true, 8); else HEADS(false, 8); }
   else if (A <= 24) { if (train) HEADS(true, 24); else HEADS(false, 24); }
   else { if (train) HEADS(true, 64); else HEADS(false, 64); }
@@ -554,7 +561,7 @@ int launch_rmsprop(ga3c_net* net, const float* grad, float* scales, const float*
 
 // forward on a prediction lane: pick the current weights under the shared lock
 // the kernels of one prediction step on lane L: the intake gather (offsets already in L.h_off), then the forward pass
-int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v) {
+int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v, hipEvent_t stop_ev = nullptr) {
   L.f.src_base = nullptr;
   L.f.src_off = nullptr;
   if (mode != STEP_RESIDENT) {
@@ -574,7 +581,7 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
       else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B, none, ro);
     }
   }
-  const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v);
+  const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v, stop_ev);
   L.f.src_base = nullptr;
   L.f.src_off = nullptr;
   L.f.src_off_host = nullptr;
@@ -587,8 +594,14 @@ void drop_graphs(Lane& L) {
 }
 
 // launch_step, replayed from the lane's graph cache (captured on first use of a shape)
-int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v) {
-  if (!net->graphs) return launch_step(net, L, idx, B, mode, out_p, out_v);
+// mark_done: L.done is recorded behind the step (the callers that will wait for it, or let a train step wait for it)
+int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, float* out_v, bool mark_done = false) {
+  if (!net->graphs) {
+    if (mark_done && net->stop_events) return launch_step(net, L, idx, B, mode, out_p, out_v, L.done);
+    CHK(launch_step(net, L, idx, B, mode, out_p, out_v));
+    if (mark_done) HIPCHK(hipEventRecord(L.done, L.st));
+    return GA3C_OK;
+  }
   const bool u8 = mode == STEP_RESIDENT ? L.f.x_u8 : mode != STEP_GATHER_F32;
   const int64_t key = ((int64_t)B << 8) | (idx << 5) | (mode << 2) | (u8 ? 2 : 0) | (out_p ? 1 : 0);
   auto it = L.graphs.find(key);
@@ -610,6 +623,7 @@ int lane_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, fl
   }
   L.f.x_u8 = u8;
   HIPCHK(hipGraphLaunch(it->second, L.st));
+  if (mark_done) HIPCHK(hipEventRecord(L.done, L.st));
   return GA3C_OK;
 }
 
@@ -643,9 +657,8 @@ int lane_forward(ga3c_net* net, Lane& L, int B, int mode, float* out_p, float* o
   }
   const int idx = net->cur.load();      // a finished step's weights: nothing to wait for
   if (net->time_predictions) HIPCHK(hipEventRecord(L.tm0, L.st));
-  CHK(lane_step(net, L, idx, B, mode, out_p, out_v));
+  CHK(lane_step(net, L, idx, B, mode, out_p, out_v, true));   // L.done: behind the step
   if (net->time_predictions) HIPCHK(hipEventRecord(L.tm1, L.st));
-  HIPCHK(hipEventRecord(L.read_done[idx], L.st));
   L.dirty[idx] = true;
   return GA3C_OK;
 }
@@ -659,7 +672,7 @@ int claim_other_buffer(ga3c_net* net, TrainLane& t, int* idx_out, int* other_out
   const int other = c == idx ? (idx + 1) % 3 : 3 - idx - c;
   for (Lane* L : net->lanes) {
     if (L->dirty[other]) {
-      HIPCHK(hipStreamWaitEvent(t.st, L->read_done[other], 0));
+      HIPCHK(hipStreamWaitEvent(t.st, L->done, 0));    // the lane's last step (at least as late as its last read of `other`)
       L->dirty[other] = false;
       stat_add(net, GA3C_STAT_TRAIN_READER_WAITS, 1);
     }
@@ -993,6 +1006,12 @@ void note_predict_span(ga3c_net* net, Lane* L) {
   if (net->time_predictions && hipEventElapsedTime(&ms, L->tm0, L->tm1) == hipSuccess) stat_add(net, GA3C_STAT_PREDICT_GPU_NS, (int64_t)(ms * 1e6f));
 }
 
+// wait for the step lane_forward enqueued last (it left L->done behind it)
+int lane_wait_step(Lane* L) {
+  HIPCHK(hipEventSynchronize(L->done));
+  return GA3C_OK;
+}
+
 // wait until everything lane L has enqueued is done (L's mutex is held)
 int lane_wait(Lane* L) {
   if (!L->shared_st) {
@@ -1015,7 +1034,8 @@ int finish_predict(ga3c_net* net, Lane* L, int B, int mode, float* p, float* v, 
   CHK(lane_forward(net, *L, B, mode, hp, hv));
   if (z) HIPCHK(hipMemcpyAsync(hz, L->f.z, (size_t)B * A * sizeof(float), hipMemcpyDeviceToHost, L->st));
   const int64_t t1 = now_ns();
-  CHK(lane_wait(L));
+  if (z) CHK(lane_wait(L));                                  // the copy is behind the step's own event
+  else CHK(lane_wait_step(L));
   note_predict_span(net, L);
   stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
   stat_add(net, GA3C_STAT_PREDICT_ROWS, B);
@@ -1353,6 +1373,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
   if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_STOP_EVENTS")) net->stop_events = atoi(e) != 0;
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
   if (const char* e = getenv("GA3C_GATHER_BLOCKS")) net->gather_max_blocks = atoi(e) > 0 ? atoi(e) : 32;
   for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true, false>), reinterpret_cast<const void*>(&conv_bwd_kernel<false, false>),
@@ -1465,7 +1486,6 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     TRY(alloc_fwd(L->f, maxB, A));
     TRYHIP(hipHostMalloc((void**)&L->h_in, (size_t)maxB * XS * sizeof(float), hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
-    for (int k = 0; k < 3; ++k) TRYHIP(hipEventCreateWithFlags(&L->read_done[k], hipEventDisableTiming));
     TRYHIP(hipHostMalloc((void**)&L->h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
   }
   TRY(alloc_train_lane(net, net->tr, net->grad));
@@ -1498,8 +1518,6 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (L->h_in) (void)hipHostFree(L->h_in);
     if (L->h_out) (void)hipHostFree(L->h_out);
     if (L->h_off) (void)hipHostFree(L->h_off);
-    for (int k = 0; k < 3; ++k)
-      if (L->read_done[k]) (void)hipEventDestroy(L->read_done[k]);
     for (hipEvent_t e : {L->done, L->tm0, L->tm1})
       if (e) (void)hipEventDestroy(e);
     if (L->st && L->owns_st) (void)hipStreamDestroy(L->st);
@@ -1706,9 +1724,8 @@ int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t
     float* hp = L->h_out;
     float* hv = hp + (size_t)net->maxB * net->A;
     rc = lane_forward(net, *L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, hp, hv);
-    // the completion event goes in right behind the step, not when _end comes to wait: recorded there it was a round trip
-    // through the queue of its own, after a step that had long finished
-    if (rc == GA3C_OK && hipEventRecord(L->done, L->st) != hipSuccess) rc = fail(GA3C_EHIP, "hipEventRecord failed");
+    // (lane_forward leaves L->done behind the step: _end only waits for it -- recorded by _end it was a round trip
+    // through the queue of its own, after a step that had long finished)
     stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, now_ns() - t0);
   }
   if (rc != GA3C_OK) {
@@ -1728,7 +1745,7 @@ int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, fl
   Lane* L = net->lanes[(size_t)ticket];
   if (!L->begun.exchange(false)) return fail(GA3C_ESTATE, "ticket %d: no batch was begun on that lane (or it was ended already)", ticket);
   const int64_t t0 = now_ns();
-  const hipError_t he = hipEventSynchronize(L->done);      // recorded by _begin, behind the step
+  const hipError_t he = hipEventSynchronize(L->done);      // left behind the step by _begin
   const int rc = he == hipSuccess ? GA3C_OK : fail(GA3C_EHIP, "hipEventSynchronize failed: %s", hipGetErrorString(he));
   if (rc == GA3C_OK) {
     note_predict_span(net, L);
@@ -1970,7 +1987,7 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
   const int64_t t0 = now_ns();
   CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
   const int64_t t1 = now_ns();
-  CHK(lane_wait(L));
+  CHK(lane_wait_step(L));
   note_predict_span(net, L);
   stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
   stat_add(net, GA3C_STAT_PREDICT_ROWS, want);
