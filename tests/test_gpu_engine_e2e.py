@@ -104,6 +104,55 @@ def test_gather_from_registered_transport_is_bit_identical_to_host_path():
         t.close()
 
 
+@pytest.mark.parametrize("switch", ["GA3C_OFFSETS_IN_ARGS", "GA3C_STOP_EVENTS"])
+def test_alternate_launch_paths_of_a_gathered_step_give_the_same_bits(monkeypatch, switch):
+    """The offsets of a scattered batch travel in the kernel arguments (GA3C_OFFSETS_IN_ARGS=0: read from pinned memory) and
+    a step's completion event is the stop event of its last launch (GA3C_STOP_EVENTS=0: a record of its own): the
+    fallbacks stay in the library (hipGraph replays use the first), so they are held to the default path bit for bit --
+    predictions on transport rows from two threads, and a train call on rollout rows."""
+    import threading
+    import ga3c_amd  # noqa: F401
+    import Transport as tp
+    from NetworkVP import Network
+    t = tp.Transport.create(tp.unique_name("t_alt"), 48, 6, 84 * 84 * 4, 8, 6)
+    rng = np.random.default_rng(21)
+    t.agent_states[:] = rng.integers(0, 256, size=(48, 84 * 84 * 4), dtype=np.uint8)
+    states, _, _ = t.rollout_views(2)
+    states[:6] = rng.integers(0, 256, size=(6, 84 * 84 * 4), dtype=np.uint8)
+    y = rng.uniform(-1, 1, 6)
+    a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, 6)]
+    outs = []
+    try:
+        for flag in ("1", "0"):
+            monkeypatch.setenv(switch, flag)
+            net = Network("gpu:0", "alt" + flag, 6, (84, 84, 4), max_batch=64, predict_lanes=2)
+            monkeypatch.delenv(switch)
+            try:
+                net.register_transport(t)
+                net.learning_rate, net.beta = 3e-4, 0.01
+                got = {}
+
+                def work(k):
+                    ids = np.arange(k, 48, 2, dtype=np.uint32)
+                    res = None
+                    for _ in range(20):
+                        res = net.predict_offsets(t.state_offsets(ids))
+                    got[k] = res
+                th = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                net.train_offsets(t.rollout_row_offsets(2, 6), y, a)
+                outs.append((got[0][0], got[0][1], got[1][0], got[1][1], net.get_arena(0)))
+            finally:
+                net.close()
+        assert all(np.array_equal(p, q) for p, q in zip(outs[0], outs[1]))
+    finally:
+        t.shutdown()
+        t.close()
+
+
 def test_gather_of_f32_states_from_registered_transport():
     """STATE_TRANSPORT = 'f32': the slots hold 28,224 floats; the fused conv stack then reads them out of the HIP-registered
     host segment by LDS-DMA (global_load_lds over PCIe).  Must equal the host-buffer path bit for bit."""
