@@ -132,10 +132,12 @@ typedef struct ga3c_serve_stats {
 } ga3c_serve_stats;
 int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
                   int32_t slice_ms, ga3c_serve_stats* stats);
-/* The same loop with the answering overlapped with the GPU: while requests are queued, batch k+1 is popped and its step
- * ENQUEUED (`begin`) before batch k is answered, so the ~1.6 us per agent that waking it costs (a futex wake each) run beside
- * the GPU's work on the next batch instead of in front of it; with nothing queued batch k is answered at once, as above.
- * `begin` / `end` have the signatures of ga3c_net_predict_gather_begin / _end (include/ga3c_abi.h).  Same return values. */
+/* The same loop with the answering off its critical path: the ~1.6 us per agent that waking it costs (a futex wake each)
+ * are spent by a helper thread of the call, as soon as `end` has returned the batch's results, while the loop pops and
+ * ENQUEUES (`begin`) the next batch.  With GA3C_RESPONDER=0 in the environment the loop answers batch k itself, after it has
+ * begun batch k+1 (beside the GPU's work on it); with nothing queued batch k is answered at once either way.  Nothing is
+ * held when the call returns.  `begin` / `end` have the signatures of ga3c_net_predict_gather_begin / _end
+ * (include/ga3c_abi.h).  Same return values. */
 typedef int (*ga3c_predict_begin_fn)(void* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket);
 typedef int (*ga3c_predict_end_fn)(void* net, int32_t ticket, int32_t batch, float* p, float* v);
 int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_end_fn end, void* net, int32_t u8,
