@@ -1003,7 +1003,9 @@ struct LaneGuard {
 // after lane_wait: the GPU span of the step lane_forward enqueued (diagnostic switch)
 void note_predict_span(ga3c_net* net, Lane* L) {
   float ms = 0.f;
-  if (net->time_predictions && hipEventElapsedTime(&ms, L->tm0, L->tm1) == hipSuccess) stat_add(net, GA3C_STAT_PREDICT_GPU_NS, (int64_t)(ms * 1e6f));
+  if (!net->time_predictions) return;
+  (void)hipEventSynchronize(L->tm1);                         // it sits behind the step's own completion event
+  if (hipEventElapsedTime(&ms, L->tm0, L->tm1) == hipSuccess) stat_add(net, GA3C_STAT_PREDICT_GPU_NS, (int64_t)(ms * 1e6f));
 }
 
 // wait for the step lane_forward enqueued last (it left L->done behind it)
