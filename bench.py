@@ -89,7 +89,8 @@ def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2, trai
         else:
             steady = dict(whole, train_rows_per_step=srv.frame_counter / max(srv.training_step, 1), mean_predict_batch=None)
         res = dict(steady, agents=agents, predictors=predictors, trainers=trainers, whole_run=whole,
-                   native_predictor_loop=bool(native and native[0]))
+                   native_predictor_loop=bool(native and native[0]),
+                   rollouts_name_their_states=bool(getattr(srv, "state_cache", False) or getattr(srv, "device_frontend", False)))
         if model is None:
             srv.model.close()
         return res

@@ -282,9 +282,11 @@ class Network:
         seqs = np.ascontiguousarray(seqs, dtype=np.int64)
         y, a = nat.as_f32(y_r), nat.as_f32(a)
         losses = np.empty(3, dtype=np.float32)
-        nat.check(self._lib.ga3c_net_train_frames(self._h, nat.ptr(agents, nat.i32p), nat.ptr(seqs, nat.i64p), nat.ptr(y),
-                                                  nat.ptr(a), agents.size, float(self.learning_rate), float(self.beta),
-                                                  nat.ptr(losses)), "ga3c_net_train_frames")
+        # with a state cache the names are (agent, request number) of states the predictions stored; otherwise planes
+        fn, name = ((self._lib.ga3c_net_train_cached, "ga3c_net_train_cached") if getattr(self, "_state_cache", False)
+                    else (self._lib.ga3c_net_train_frames, "ga3c_net_train_frames"))
+        nat.check(fn(self._h, nat.ptr(agents, nat.i32p), nat.ptr(seqs, nat.i64p), nat.ptr(y), nat.ptr(a), agents.size,
+                     float(self.learning_rate), float(self.beta), nat.ptr(losses)), name)
         self.last_losses = losses
 
     def frame_state(self, agent):
@@ -334,6 +336,19 @@ class Network:
     def gather_entries_pipelined(self):
         """(addresses of ga3c_net_predict_gather_begin / _end, engine handle, u8 flag) for ga3c_pq_serve_pipelined."""
         return (C.cast(self._lib.ga3c_net_predict_gather_begin, C.c_void_p).value,
+                C.cast(self._lib.ga3c_net_predict_gather_end, C.c_void_p).value, self._h, int(self._transport_u8))
+
+    def state_cache_config(self, max_agents, depth):
+        """Keep the uint8 states the pipelined predictor loop reads, `depth` per agent (ga3c_net_state_cache_config): rows of
+        a train batch may then be named (agent, request number) -- train_frames / evaluate(frames=...) take such names."""
+        nat.check(self._lib.ga3c_net_state_cache_config(self._h, int(max_agents), int(depth)), "ga3c_net_state_cache_config")
+        self._state_cache = True
+
+    def gather_entries_pipelined_cached(self):
+        """As gather_entries_pipelined, with ga3c_net_predict_gather_begin_cached (None without a state cache)."""
+        if not getattr(self, "_state_cache", False):
+            return None
+        return (C.cast(self._lib.ga3c_net_predict_gather_begin_cached, C.c_void_p).value,
                 C.cast(self._lib.ga3c_net_predict_gather_end, C.c_void_p).value, self._h, int(self._transport_u8))
 
     def predict_offsets(self, offsets):
@@ -431,8 +446,10 @@ class Network:
         if frames is not None:
             agents = np.ascontiguousarray(frames[0], dtype=np.int32)
             seqs = np.ascontiguousarray(frames[1], dtype=np.int64)
-            nat.check(self._lib.ga3c_net_evaluate_frames(self._h, nat.ptr(agents, nat.i32p), nat.ptr(seqs, nat.i64p), nat.ptr(y),
-                                                         nat.ptr(a), b, float(self.beta), *outs), "ga3c_net_evaluate_frames")
+            fn, name = ((self._lib.ga3c_net_evaluate_cached, "ga3c_net_evaluate_cached") if getattr(self, "_state_cache", False)
+                        else (self._lib.ga3c_net_evaluate_frames, "ga3c_net_evaluate_frames"))
+            nat.check(fn(self._h, nat.ptr(agents, nat.i32p), nat.ptr(seqs, nat.i64p), nat.ptr(y), nat.ptr(a), b,
+                         float(self.beta), *outs), name)
         elif offsets is not None:
             offsets = np.ascontiguousarray(offsets, dtype=np.int64)
             nat.check(self._lib.ga3c_net_evaluate(self._h, None, None, nat.ptr(offsets, nat.i64p), int(self._transport_u8),

@@ -51,6 +51,8 @@ class ProcessAgent(MP.Process):
         # device front-end: frames handed over under this id so far = sequence number of the next plane (not 0 when the
         # id was another agent's before: the device keeps counting, Server.add_agent)
         self.planes_pushed = int(planes_pushed)
+        self.requests = 0                # number of this id's newest request (run() reads where the id's counter stands)
+        self.names_states = False        # STATE_CACHE_ACTIVE: experiences name their state by that number
 
     # ---- pieces with the reference's names and semantics ------------------------------------
     @staticmethod
@@ -83,6 +85,7 @@ class ProcessAgent(MP.Process):
         slot[:] = state.reshape(-1)
         if self.transport.submit(self.id) == tp.CLOSED:     # nothing was queued: waiting would return the previous answer
             raise SystemExit(0)
+        self.requests += 1                                  # = this request's number (ga3c_pq_request_seq)
         while True:
             rc, p, v = self.transport.wait(self.id, Config.QUEUE_TIMEOUT_MS)
             if rc == 0:
@@ -137,8 +140,11 @@ class ProcessAgent(MP.Process):
             action = self.select_action(self.actions, prediction)
             reward, done = self.env.step(action)
             reward_sum += reward
-            next_state = self.env.current_u8 if as_u8 else self.env.current_state
-            experiences.append(Experience(state, action, prediction, reward, next_state, done))
+            if self.names_states:               # the engine kept the state this request carried: the experience names it
+                experiences.append(Experience(self.requests, action, prediction, reward, None, done))
+            else:
+                next_state = self.env.current_u8 if as_u8 else self.env.current_state
+                experiences.append(Experience(state, action, prediction, reward, next_state, done))
             if done or self.time_count == Config.TIME_MAX:
                 if Config.RETURN_MODE == 'nstep':
                     terminal_reward = 0.0 if done else float(value)
@@ -193,7 +199,7 @@ class ProcessAgent(MP.Process):
         states, returns, actions = self.transport.rollout_views(slot)
         n = len(experiences)
         for i, e in enumerate(experiences):
-            if self.env.on_device:              # row = (plane sequence number, agent id): the state itself is in HBM
+            if self.env.on_device or self.names_states:   # row = (plane / request number, agent id): the state itself is in HBM
                 states[i, :8].view(np.int64)[0] = e.state
                 states[i, 8:12].view(np.int32)[0] = self.id
             else:
@@ -206,6 +212,8 @@ class ProcessAgent(MP.Process):
         for k, v in self.config.items():
             setattr(Config, k, v)
         self.transport = tp.Transport.attach(self.transport_name)
+        self.names_states = bool(getattr(Config, "STATE_CACHE_ACTIVE", False))
+        self.requests = self.transport.request_seq(self.id)   # (not 0 when the id was another agent's before)
         self.env = Environment(self.id)
         self.num_actions = self.env.get_num_actions()
         self.actions = np.arange(self.num_actions)

@@ -8,6 +8,7 @@ What changed against the reference, and why:
     TensorFlow class (Server.py:48-54);
   * agents are started from a forkserver, so they never inherit the server's HIP state.
 """
+import os
 import threading
 import time
 
@@ -44,12 +45,25 @@ class Server:
         if self.device_frontend:
             state_bytes = (self.frame_shape[0] * self.frame_shape[1] * self.frame_shape[2] + 15) // 16 * 16
             row_bytes = 16
+        # State cache: the engine keeps the uint8 states its predictions read and rollouts name them (agent, request number)
+        # instead of carrying them -- a trainer's batch no longer crosses PCIe a second time (include/ga3c_abi.h).  Only with
+        # everything it rests on: the GPU reading the transport itself, uint8 states, the native pipelined predictor loop,
+        # batches within the fused conv stack's range, plain launches; anything else keeps the states in the rollouts.
+        model_cls = Network if model is None else type(model)
+        self.state_cache = bool(getattr(Config, "STATE_CACHE", False) and not self.device_frontend and Config.ZERO_COPY and
+                                Config.STATE_TRANSPORT == 'u8' and getattr(Config, "NATIVE_PREDICTOR", True) and
+                                getattr(Config, "PIPELINED_PREDICTOR", True) and getattr(Config, "NATIVE_TRAINER", True) and
+                                Config.PREDICTION_BATCH_SIZE <= 128 and not os.environ.get("GA3C_GRAPHS") and
+                                hasattr(model_cls, "state_cache_config") and hasattr(model_cls, "gather_entries_pipelined_cached"))
+        Config.STATE_CACHE_ACTIVE = self.state_cache         # (the agents read it from their configuration snapshot)
+        if self.state_cache:
+            row_bytes = 16
         # training_q.get() frees a queue entry at once (ThreadTrainer.py:49); zero-copy trainers keep a rollout's slot
         # until the GPU has read it, so the slots they hold come on top of the queue bound
         slots = int(Config.ROLLOUT_SLOTS)
         if slots <= 0:
             per_batch = -(-(Config.TRAINING_MIN_BATCH_SIZE + 1) // max(Config.TIME_MAX, 1))
-            slots = Config.MAX_QUEUE_SIZE + (0 if self.device_frontend else 2 * max(Config.TRAINERS, 2) * per_batch)
+            slots = Config.MAX_QUEUE_SIZE + (0 if (self.device_frontend or self.state_cache) else 2 * max(Config.TRAINERS, 2) * per_batch)
         self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
                                              slots, Config.TIME_MAX + 1, row_bytes)
         if Config.PREDICTION_LINGER_US > 0:
@@ -71,6 +85,14 @@ class Server:
             history = Config.FRAME_HISTORY or ((self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8 +
                                                max(Config.TRAINERS, 2) * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1))
             self.model.frames_config(self.max_agents, self.frame_shape[0], self.frame_shape[1], self.frame_shape[2], history)
+        if self.state_cache:
+            if not self.zero_copy:
+                raise RuntimeError("STATE_CACHE needs a model that reads the transport itself (register_transport)")
+            # how far an agent can be ahead of the trainers: every rollout in flight plus the one it is filling, plus the rows
+            # every trainer may hold after it has given their slots back (the bound of the plane history above)
+            depth = (self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8 + \
+                max(Config.TRAINERS, 2) * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1)
+            self.model.state_cache_config(self.max_agents, depth)
         if Config.LOAD_CHECKPOINT:
             try:
                 self.stats.episode_count.value = self.model.load()

@@ -42,8 +42,13 @@ class ThreadPredictor(Thread):
         # answering batch k beside the GPU's work on batch k+1 (ga3c_pq_serve_pipelined) when the model offers the split call
         split = getattr(self.server.model, "gather_entries_pipelined", None) if getattr(Config, "PIPELINED_PREDICTOR", True) else None
         begin_end = split() if split else None
+        # ... and, with the engine's state cache in use, telling it each row's name (agent, request number)
+        cached = getattr(self.server.model, "gather_entries_pipelined_cached", None) if getattr(self.server, "state_cache", False) else None
+        cached = cached() if cached else None
         while not self.exit_flag:
-            if begin_end:
+            if cached:
+                rc = t.serve_pipelined_cached(cached[0], cached[1], handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+            elif begin_end:
                 rc = t.serve_pipelined(begin_end[0], begin_end[1], handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
             else:
                 rc = t.serve(entry, handle, u8, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)

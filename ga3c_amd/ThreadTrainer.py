@@ -47,7 +47,9 @@ class ThreadTrainer(Thread):
         alloc = getattr(self.server.model, "pinned_array", None)
         shape = (cap, t.state_bytes)
         zero_copy = getattr(self.server, "zero_copy", False)
-        on_device = getattr(self.server, "device_frontend", False)     # rows name states kept in HBM: (plane seq, agent)
+        # rows name states kept in HBM: (plane number, agent) with the frame queue on the device, (request number, agent) with
+        # the engine's state cache
+        on_device = getattr(self.server, "device_frontend", False) or getattr(self.server, "state_cache", False)
         seq_stage = np.zeros(cap, np.int64)
         agent_stage = np.zeros(cap, np.int32)
         x_stage = None

@@ -126,6 +126,18 @@ class Transport:
                                                C.addressof(stats))
         return nat.check_host(rc, "ga3c_pq_serve_pipelined")
 
+    def serve_pipelined_cached(self, begin, end, net_handle, u8, max_batch, slice_ms, stats):
+        """serve_pipelined for an engine that keeps the states it reads (`begin`: ga3c_net_predict_gather_begin_cached)."""
+        rc = self._lib.ga3c_pq_serve_pipelined_cached(self._h, begin, end, net_handle, int(u8), int(max_batch), int(slice_ms),
+                                                      C.addressof(stats))
+        return nat.check_host(rc, "ga3c_pq_serve_pipelined_cached")
+
+    def request_seq(self, agent):
+        """Number of `agent`'s newest request (in flight or answered last): the name of the state it carried."""
+        n = C.c_int64()
+        nat.check_host(self._lib.ga3c_pq_request_seq(self._h, int(agent), C.byref(n)), "ga3c_pq_request_seq")
+        return n.value
+
     def set_linger(self, linger_us, min_batch):
         nat.check_host(self._lib.ga3c_pq_set_linger(self._h, int(linger_us), int(min_batch)), "ga3c_pq_set_linger")
 

@@ -74,6 +74,10 @@ HIP_SIGNATURES = {
     "ga3c_net_frames_push_offsets": (C.c_int, [C.c_void_p, i64p, i32p, u8p, C.c_int32, i64p]),
     "ga3c_net_serve_frames": (C.c_int, [C.c_void_p, i64p, i32p, u32p, C.c_int32, f32p, f32p]),
     "ga3c_net_train_frames": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
+    "ga3c_net_train_cached": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
+    "ga3c_net_evaluate_cached": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, f32p, f32p, f32p, f32p]),
+    "ga3c_net_state_cache_config": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ga3c_net_predict_gather_begin_cached": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), i32p, i64p, C.c_int32, C.c_int32, i32p]),
     "ga3c_net_frames_state": (C.c_int, [C.c_void_p, C.c_int32, u8p, i32p]),
     "ga3c_net_predict_frames": (C.c_int, [C.c_void_p, i32p, C.c_int32, f32p, f32p, f32p]),
     "ga3c_net_frames_pushed": (C.c_int, [C.c_void_p, C.c_int32, i64p]),
@@ -122,6 +126,8 @@ HOST_SIGNATURES = {
     "ga3c_pq_wait": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_int32]),
     "ga3c_select_action": (C.c_int32, [f32p, C.c_int32, C.c_double]),
     "ga3c_pq_serve_pipelined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ga3c_pq_serve_pipelined_cached": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "ga3c_pq_request_seq": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "ga3c_frame_queue_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),   # (plane: address or bytes)
     "ga3c_pq_agent_idle": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_pq_pop_batch": (C.c_int, [C.c_void_p, u32p, C.c_int32, C.c_int32]),

@@ -52,8 +52,10 @@ int fail(int code, const char* fmt, ...) {
 #define HIPCHK(expr)                                                                              \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \
-    if (_e != hipSuccess) return fail(GA3C_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
-                                      __FILE__, __LINE__);                                        \
+    if (_e != hipSuccess) {                                                                       \
+      (void)hipGetLastError(); /* reported here: it must not surface again behind a later launch */ \
+      return fail(GA3C_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    }                                                                                             \
   } while (0)
 #define NCCLCHK(expr)                                                                             \
   do {                                                                                            \
@@ -90,6 +92,7 @@ struct Fwd {   // forward workspace of one lane (device pointers)
   const uint8_t* src_base = nullptr;
   const int64_t* src_off = nullptr;
   const int64_t* src_off_host = nullptr;   // the same array as the host sees it (pinned: same address; kept apart for clarity)
+  const int64_t* cache_dst = nullptr;      // per row: where in the state cache the conv stack stores the uint8 state it stages
 };
 
 struct Lane {
@@ -99,6 +102,8 @@ struct Lane {
   bool shared_st = false;     // another lane enqueues on `st` too: completion is waited for on `done`, not on the stream
   int sidx = 0;               // which of the prediction streams `st` is (index into ga3c_net::stream_busy)
   std::atomic<bool> begun{false};   // taken by ga3c_net_predict_gather_begin, to be given back by _end
+  int64_t cache_dst[128];           // byte offsets into the state cache of the batch begun with _begin_cached
+  bool cache_on = false;
   hipEvent_t done = nullptr;
   hipEvent_t tm0 = nullptr, tm1 = nullptr;   // timing events of ga3c_net_time_predict_lanes
   Fwd f;
@@ -266,6 +271,13 @@ struct ga3c_net {
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
                                        // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
+  // State cache (ga3c_net_state_cache_config): the uint8 states the prediction steps read out of the transport, kept in HBM
+  // in a ring of `depth` per agent, slot = request number % depth -- a train batch then names its rows (agent, request
+  // number) and is gathered HBM to HBM instead of crossing PCIe a second time.
+  uint8_t* cache_ring = nullptr;
+  int cache_agents = 0, cache_depth = 0;
+  std::mutex cache_mu;
+  std::vector<int64_t> cache_newest;   // per agent: the newest request number stored (-1: none)
   bool stop_events = true;             // GA3C_STOP_EVENTS=0: a prediction step's completion event is a hipEventRecord of its own
   bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
   bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
@@ -403,13 +415,18 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
     const size_t lds = CS_LDS_FLOATS * sizeof(float);
     SrcOffsets so;
     so.n = 0;
+    so.n_dst = 0;
     if (f.src_off && f.src_off_host && !net->graphs && net->offsets_in_args) {   // plain launch: the offsets ride in the kernel arguments
       memcpy(so.off, f.src_off_host, (size_t)B * sizeof(int64_t));
       so.n = B;
     }
+    if (f.cache_dst && f.src_off && f.x_u8 && !train && !net->graphs) {           // the state cache takes a copy of what is staged
+      memcpy(so.dst, f.cache_dst, (size_t)B * sizeof(int64_t));
+      so.n_dst = B;
+    }
 #define CSTACK(T, U)                                                                                                \
   hipLaunchKernelGGL((conv_stack_fwd_kernel<T, U>), dim3(B * 2), dim3(1024), lds, st, xin, net->theta_pk[idx] + PK_W1F, th + OFF_B1, \
-                     net->theta_pk[idx] + PK_W2F, th + OFF_B2, f.n1, f.n2, B, f.src_off, so)
+                     net->theta_pk[idx] + PK_W2F, th + OFF_B2, f.n1, f.n2, B, f.src_off, so, net->cache_ring)
     if (train) { if (f.x_u8) CSTACK(true, true); else CSTACK(true, false); }
     else { if (f.x_u8) CSTACK(false, true); else CSTACK(false, false); }
 #undef CSTACK
@@ -573,6 +590,7 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
       L.f.src_base = base;
       L.f.src_off = L.h_off;
       L.f.src_off_host = L.h_off;
+      L.f.cache_dst = (L.cache_on && mode == STEP_GATHER_U8) ? L.cache_dst : nullptr;
     } else {
       const SmallCopy none{nullptr, nullptr, 0, nullptr, nullptr, 0};
       RowOffsets ro;
@@ -585,6 +603,7 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
   L.f.src_base = nullptr;
   L.f.src_off = nullptr;
   L.f.src_off_host = nullptr;
+  L.f.cache_dst = nullptr;
   return rc;
 }
 
@@ -1510,6 +1529,7 @@ int ga3c_net_destroy(ga3c_net* net) {
   stop_lane_drivers(net);
   (void)hipSetDevice(net->cfg.device);
   (void)hipDeviceSynchronize();
+  if (net->cache_ring) (void)hipFree(net->cache_ring);
   if (net->comm) (void)ncclCommDestroy(net->comm);
   if (net->cst) (void)hipStreamDestroy(net->cst);
   for (hipEvent_t e : {net->ev_tail_ready, net->ev_head_ready, net->ev_comm_done})
@@ -1709,9 +1729,36 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
   return finish_predict(net, L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, p, v, z);
 }
 
-int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket) {
+// rows' slots in the state cache, checked: row i = (agents[i], seqs[i]) -> byte offset; `advance`: they are being STORED
+// (the newest request number of an agent moves on), otherwise they are being READ and must still be there
+static int cache_offsets(ga3c_net* net, const int32_t* agents, const int64_t* seqs, int batch, bool advance, int64_t* out) {
+  if (!net->cache_ring) return fail(GA3C_ESTATE, "no state cache configured (ga3c_net_state_cache_config)");
+  std::lock_guard<std::mutex> g(net->cache_mu);
+  for (int i = 0; i < batch; ++i) {
+    const int ag = agents[i];
+    if (ag < 0 || ag >= net->cache_agents) return fail(GA3C_EINVAL, "state cache: agent %d outside [0,%d)", ag, net->cache_agents);
+    if (seqs[i] < 0) return fail(GA3C_EINVAL, "state cache: row %d has a negative request number", i);
+    int64_t& newest = net->cache_newest[(size_t)ag];
+    if (advance) {
+      if (seqs[i] > newest) newest = seqs[i];
+    } else if (seqs[i] > newest || newest - seqs[i] >= net->cache_depth) {
+      return fail(GA3C_ESTATE, "state cache: row %d, request %lld of agent %d, is not held (newest %lld, depth %d)", i,
+                  (long long)seqs[i], ag, (long long)newest, net->cache_depth);
+    }
+    out[i] = ((int64_t)ag * net->cache_depth + seqs[i] % net->cache_depth) * (int64_t)XS;
+  }
+  return GA3C_OK;
+}
+
+static int predict_begin_common(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs, int32_t batch,
+                                int32_t u8, int32_t* ticket) {
   if (!net || !offsets || !ticket) return fail(GA3C_EINVAL, "null argument");
   HIPCHK(hipSetDevice(net->cfg.device));
+  if (agents) {
+    if (!seqs) return fail(GA3C_EINVAL, "null argument");
+    if (!u8 || net->graphs || !net->fused_conv || batch > FUSED_CONV_MAX_B || batch > 128)
+      return fail(GA3C_ESTATE, "the state cache is filled by plain launches of the fused conv stack on uint8 states (batch <= 128)");
+  }
   Lane* L = take_lane(net);                                  // stays taken until ga3c_net_predict_gather_end
   net->predict_inflight.fetch_add(1, std::memory_order_relaxed);
   auto give_back = [&]() {
@@ -1720,16 +1767,22 @@ int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t
     L->mu.unlock();
   };
   int rc = stage_offsets(net, offsets, batch, u8 != 0, L->h_off);
+  L->cache_on = false;
+  if (rc == GA3C_OK && agents) {
+    rc = cache_offsets(net, agents, seqs, batch, true, L->cache_dst);
+    L->cache_on = rc == GA3C_OK;
+  }
   if (rc == GA3C_OK) {
     TraceRange range("ga3c.predict.begin");
     const int64_t t0 = now_ns();
     float* hp = L->h_out;
     float* hv = hp + (size_t)net->maxB * net->A;
-    rc = lane_forward(net, *L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, hp, hv);
     // (lane_forward leaves L->done behind the step: _end only waits for it -- recorded by _end it was a round trip
     // through the queue of its own, after a step that had long finished)
+    rc = lane_forward(net, *L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, hp, hv);
     stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, now_ns() - t0);
   }
+  L->cache_on = false;
   if (rc != GA3C_OK) {
     give_back();
     return rc;
@@ -1738,6 +1791,16 @@ int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t
     if (net->lanes[i] == L) *ticket = (int32_t)i;
   L->begun.store(true);
   return GA3C_OK;
+}
+
+int ga3c_net_predict_gather_begin(ga3c_net* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket) {
+  return predict_begin_common(net, offsets, nullptr, nullptr, batch, u8, ticket);
+}
+
+int ga3c_net_predict_gather_begin_cached(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs,
+                                         int32_t batch, int32_t u8, int32_t* ticket) {
+  if (!agents || !seqs) return fail(GA3C_EINVAL, "null argument");
+  return predict_begin_common(net, offsets, agents, seqs, batch, u8, ticket);
 }
 
 int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, float* p, float* v) {
@@ -2027,6 +2090,63 @@ int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t
       [](TrainLane&, Intake&) { return (int)GA3C_OK; });
 }
 
+// ---- state cache --------------------------------------------------------------------------------------------
+int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth) {
+  if (!net) return fail(GA3C_EINVAL, "null argument");
+  if (max_agents < 1 || depth < 2) return fail(GA3C_EINVAL, "state cache: %d agents x %d states", max_agents, depth);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  CHK(sync_all(net));
+  std::lock_guard<std::mutex> g(net->cache_mu);
+  if (net->cache_ring) (void)hipFree(net->cache_ring);
+  net->cache_ring = nullptr;
+  const size_t bytes = (size_t)max_agents * depth * XS;
+  if (hipMalloc((void**)&net->cache_ring, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(GA3C_EHIP, "state cache: cannot allocate %zu bytes (%d agents x %d states)", bytes, max_agents, depth);
+  }
+  net->cache_agents = max_agents;
+  net->cache_depth = depth;
+  net->cache_newest.assign((size_t)max_agents, -1);
+  return GA3C_OK;
+}
+
+// rows named (agent, request number) -> the intake's uint8 rows, HBM to HBM; returns / actions as for any staged batch
+static int stage_cached_rows(ga3c_net* net, Stage& s, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                             int32_t batch) {
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
+  CHK(cache_offsets(net, agents, seqs, batch, false, s.h_off));
+  float* hy = s.h_in + (size_t)net->maxB * XS;
+  float* ha = hy + net->maxB;
+  SmallCopy sc{nullptr, nullptr, 0, nullptr, nullptr, 0};
+  if (y_r) { memcpy(hy, y_r, (size_t)batch * sizeof(float)); sc.src0 = hy; sc.dst0 = s.yr; sc.n0 = batch; }
+  if (a) { memcpy(ha, a, (size_t)batch * net->A * sizeof(float)); sc.src1 = ha; sc.dst1 = s.act; sc.n1 = batch * net->A; }
+  RowOffsets ro;
+  ro.n = 0;
+  if (batch <= 192) { memcpy(ro.off, s.h_off, (size_t)batch * sizeof(int64_t)); ro.n = batch; }
+  // (reads HBM, not the bus: wide is fine, and the rows are there in a few microseconds)
+  hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(batch, XS / 16, 256)), dim3(256), 0, s.st, net->cache_ring, s.h_off,
+                     reinterpret_cast<uint4*>(s.xu8), batch, sc, ro);
+  HIPCHK(hipGetLastError());
+  s.x_u8 = true;
+  return GA3C_OK;
+}
+
+int ga3c_net_train_cached(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                          int32_t batch, float learning_rate, float beta, float* losses) {
+  if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  return with_staged_batch(net, batch, [&](Stage& s) { return stage_cached_rows(net, s, agents, seqs, y_r, a, batch); },
+                           [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
+                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
+}
+
+int ga3c_net_evaluate_cached(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                             int32_t batch, float beta, float* losses, float* d1, float* v, float* p) {
+  if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
+  return with_staged_batch(net, batch, [&](Stage& s) { return stage_cached_rows(net, s, agents, seqs, y_r, a, batch); },
+                           [&](TrainLane& t, Intake&) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); },
+                           [](TrainLane&, Intake&) { return (int)GA3C_OK; });
+}
+
 int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed) {
   if (!net || !pushed) return fail(GA3C_EINVAL, "null argument");
   Frames& f = net->fr;
@@ -2300,15 +2420,15 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "conv_stack_fwd") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
-                            (const int64_t*)nullptr, SrcOffsets{});
+                            (const int64_t*)nullptr, SrcOffsets{}, (uint8_t*)nullptr);
     } else if (k == "conv_stack_fwd_train") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<true, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
-                            (const int64_t*)nullptr, SrcOffsets{});
+                            (const int64_t*)nullptr, SrcOffsets{}, (uint8_t*)nullptr);
     } else if (k == "conv_stack_fwd_u8") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.xu8, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,
-                            (const int64_t*)nullptr, SrcOffsets{});
+                            (const int64_t*)nullptr, SrcOffsets{}, (uint8_t*)nullptr);
     } else if (k == "dense1_fwd" || k == "dense1_fwd_frag") {
       const bool keep = net->d1f_tile;
       if (k == "dense1_fwd_frag") net->d1f_tile = false;

@@ -182,7 +182,8 @@ struct AgentMeta {   // lives right behind each agent's state bytes
   uint32_t req_seq;                  // written by the agent only
   std::atomic<uint32_t> resp_seq;    // futex word: predictor -> agent
   uint32_t req_flags;                // written by the agent before it submits (GA3C_REQ_*), read by the predictor
-  uint32_t pad[60];
+  uint32_t req_epoch;                // times req_seq has wrapped (written by the agent only): request number = epoch << 32 | seq
+  uint32_t pad[59];
 };
 static_assert(sizeof(AgentMeta) == 512, "AgentMeta must stay 512 bytes");
 
@@ -704,11 +705,21 @@ int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags) {
     return fail(GA3C_H_EINVAL, "agent %d already has a request in flight", agent);
   m->req_flags = flags;
   m->req_seq += 1;
+  if (m->req_seq == 0) m->req_epoch += 1;
   std::atomic_thread_fence(std::memory_order_release);   // state bytes before the id becomes visible
   if (!ring_push(shm->base, &h->req, (uint32_t)agent, &h->closed)) {
+    if (m->req_seq == 0) m->req_epoch -= 1;
     m->req_seq -= 1;
     return GA3C_H_ECLOSED;
   }
+  return GA3C_H_OK;
+}
+
+static inline int64_t request_number(const AgentMeta* m) { return ((int64_t)m->req_epoch << 32) | (int64_t)m->req_seq; }
+
+int ga3c_pq_request_seq(ga3c_shm* shm, int32_t agent, int64_t* seq) {
+  if (!shm || !seq || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad argument");
+  *seq = request_number(shm->meta(agent));
   return GA3C_H_OK;
 }
 
@@ -901,16 +912,18 @@ struct Responder {
   }
 };
 
-int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_end_fn end, void* net, int32_t u8,
-                            int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* st) {
-  if (!shm || !begin || !end || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
+static int serve_pipelined_common(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_begin_cached_fn begin_cached,
+                                  ga3c_predict_end_fn end, void* net, int32_t u8, int32_t max_batch, int32_t slice_ms,
+                                  ga3c_serve_stats* st) {
+  if (!shm || (!begin && !begin_cached) || !end || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
   Header* h = shm->hdr();
   const int A = h->cfg.num_actions;
   // two batches in flight: `cur` is being computed while `prev` (results already fetched) is answered
   std::vector<uint32_t> ids[2] = {std::vector<uint32_t>((size_t)max_batch), std::vector<uint32_t>((size_t)max_batch)};
   std::vector<float> p[2] = {std::vector<float>((size_t)max_batch * A), std::vector<float>((size_t)max_batch * A)};
   std::vector<float> v[2] = {std::vector<float>((size_t)max_batch), std::vector<float>((size_t)max_batch)};
-  std::vector<int64_t> offs((size_t)max_batch);
+  std::vector<int64_t> offs((size_t)max_batch), seqs((size_t)max_batch);
+  std::vector<int32_t> agents((size_t)max_batch);
   int cur = 0, n_prev = 0;
   const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
   const char* he = getenv("GA3C_RESPONDER");
@@ -954,8 +967,13 @@ int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_pre
           return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[cur][i]);
         }
         offs[i] = h->agents_off + (int64_t)ids[cur][i] * h->agent_stride;
+        if (begin_cached) {                                  // the row's name in the engine's state cache
+          agents[i] = (int32_t)ids[cur][i];
+          seqs[i] = request_number(shm->meta((int)ids[cur][i]));
+        }
       }
-      const int rc = begin(net, offs.data(), n, u8, &ticket);
+      const int rc = begin_cached ? begin_cached(net, offs.data(), agents.data(), seqs.data(), n, u8, &ticket)
+                                  : begin(net, offs.data(), n, u8, &ticket);
       if (rc < 0) {
         (void)answer_prev();
         return fail(GA3C_H_ECALLBACK, "predict callback (begin) failed with %d on a batch of %d", rc, n);
@@ -984,6 +1002,18 @@ int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_pre
       return rr;
     }
   }
+}
+
+int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_end_fn end, void* net, int32_t u8,
+                            int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* st) {
+  if (!begin) return fail(GA3C_H_EINVAL, "bad argument");
+  return serve_pipelined_common(shm, begin, nullptr, end, net, u8, max_batch, slice_ms, st);
+}
+
+int ga3c_pq_serve_pipelined_cached(ga3c_shm* shm, ga3c_predict_begin_cached_fn begin, ga3c_predict_end_fn end, void* net,
+                                   int32_t u8, int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* st) {
+  if (!begin) return fail(GA3C_H_EINVAL, "bad argument");
+  return serve_pipelined_common(shm, nullptr, begin, end, net, u8, max_batch, slice_ms, st);
 }
 
 int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, int32_t max_batch, int32_t slice_ms,

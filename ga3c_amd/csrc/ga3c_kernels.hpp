@@ -106,13 +106,13 @@ __device__ __forceinline__ float wave_max(float v) {
 // The kernels that read the states take them either as the f32 tensor the reference feeds (NetworkVP.py:252) or as
 // the uint8 frames they were made from (Environment.py:59-60), converting `k/128 - 1` while staging (exact in f32),
 // so uint8 batches never exist as f32 in HBM.
+__device__ __forceinline__ f32x4 px_from_u8(unsigned k) {   // the four channels of a pixel, k / 128 - 1 each
+  return (f32x4){(float)(k & 255u) * 0.0078125f - 1.0f, (float)((k >> 8) & 255u) * 0.0078125f - 1.0f,
+                 (float)((k >> 16) & 255u) * 0.0078125f - 1.0f, (float)(k >> 24) * 0.0078125f - 1.0f};
+}
 template <bool U8>
 __device__ __forceinline__ f32x4 load_px(const void* __restrict__ x, size_t sample, int pix) {
-  if (U8) {
-    const unsigned k = reinterpret_cast<const unsigned*>(x)[sample * (XS / 4) + pix];
-    return (f32x4){(float)(k & 255u) * 0.0078125f - 1.0f, (float)((k >> 8) & 255u) * 0.0078125f - 1.0f,
-                   (float)((k >> 16) & 255u) * 0.0078125f - 1.0f, (float)(k >> 24) * 0.0078125f - 1.0f};
-  }
+  if (U8) return px_from_u8(reinterpret_cast<const unsigned*>(x)[sample * (XS / 4) + pix]);
   return ld4(reinterpret_cast<const float*>(x) + sample * XS + (size_t)pix * 4);
 }
 
@@ -392,7 +392,9 @@ __device__ __forceinline__ void cs_n1_pixel(int h, int m, int& row, int& col) {
 // The byte offsets of a scattered batch travelling with the launch (kernel arguments live in device memory: a scalar load
 // out of HBM) instead of being read out of the pinned host array the caller filled -- that read was a PCIe round trip of its
 // own in front of the staging loads that depend on it.  n = 0: read src_off (hipGraph replays: arguments are baked in).
-struct SrcOffsets { int64_t off[128]; int n; };
+// dst (n_dst > 0): the workgroups of sample b also store the uint8 state they stage at cache + dst[b] (the state cache:
+// a train batch can then NAME the state instead of carrying it over the bus a second time; ga3c_net_state_cache_config).
+struct SrcOffsets { int64_t off[128]; int64_t dst[128]; int n; int n_dst; };
 
 // w1f / w2f: the filter banks in forward fragment order (theta_pk + PK_W1F / PK_W2F)
 template <bool TRAIN, bool U8>
@@ -400,7 +402,8 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
                                                              const float* __restrict__ b1, const float* __restrict__ w2f,
                                                              const float* __restrict__ b2, float* __restrict__ n1,
                                                              float* __restrict__ n2, int B,
-                                                             const int64_t* __restrict__ src_off, const SrcOffsets so) {
+                                                             const int64_t* __restrict__ src_off, const SrcOffsets so,
+                                                             uint8_t* __restrict__ cache) {
   extern __shared__ __attribute__((aligned(16))) float cs_lds[];
   float* img = cs_lds;
   float* n1l = cs_lds + CS_X_FLOATS;
@@ -448,7 +451,10 @@ __global__ __launch_bounds__(1024) void conv_stack_fwd_kernel(const void* __rest
       else if (idx < npx)
         *reinterpret_cast<f32x4*>(&img[idx * 4]) = zero4();
     } else {
-      sx[i] = ok ? load_px<U8>(xs, sb, yy * IMG + xx) : zero4();
+      const unsigned k = ok ? reinterpret_cast<const unsigned*>(xs)[sb * (XS / 4) + yy * IMG + xx] : 0u;
+      sx[i] = ok ? px_from_u8(k) : zero4();
+      // the state cache keeps the bytes as they came: each half stores the image rows it owns (0..41 | 42..83), once
+      if (so.n_dst && ok && (h ? yy >= IMG / 2 : yy < IMG / 2)) reinterpret_cast<unsigned*>(cache + so.dst[b])[yy * IMG + xx] = k;
     }
   }
 #pragma unroll

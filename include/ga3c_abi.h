@@ -154,6 +154,23 @@ int ga3c_net_predict_gather_end(ga3c_net* net, int32_t ticket, int32_t batch, fl
 int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses);
 
+/* State cache (round 3): every state a trainer gathers out of the transport crossed PCIe once already, for its prediction --
+ * and the gather's bursts on the bus are what training costs the predictions (profiles/README.md).  With a cache configured,
+ * ga3c_net_predict_gather_begin_cached also keeps the uint8 state of every row it reads in HBM, in a ring of `depth`
+ * states per agent: row i is named (agents[i], seqs[i]) -- the agent's id and the number of the request that carried the
+ * state (ga3c_pq_request_seq, include/ga3c_host.h) -- and lands in slot seqs[i] % depth of its agent.  A train batch then
+ * names its rows the same way (ProcessAgent.py:88-100 ships the state itself; NetworkVP.py:254-257 feeds it) and is
+ * gathered HBM to HBM: ga3c_net_train_cached / ga3c_net_evaluate_cached = ga3c_net_train_gather / ga3c_net_evaluate on
+ * those rows, bit for bit.  A row whose request is not held (never stored, or more than `depth` requests of its agent
+ * ago) is refused with GA3C_ESTATE.  uint8 states, plain launches of the fused conv stack (batch <= 128, no GA3C_GRAPHS). */
+int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth);
+int ga3c_net_predict_gather_begin_cached(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs,
+                                         int32_t batch, int32_t u8, int32_t* ticket);
+int ga3c_net_train_cached(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                          int32_t batch, float learning_rate, float beta, float* losses);
+int ga3c_net_evaluate_cached(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
+                             int32_t batch, float beta, float* losses, float* d1, float* v, float* p);
+
 /* Frame front-end on the device: Environment._rgb2gray + _preprocess
  * (ga3c/Environment.py:52-60) and the 4-deep frame queue of :62-74, so that an actor ships only the emulator's raw
  * RGB frame and the [84,84,4] state never leaves HBM.  The arithmetic is the reference's, bit for bit (see

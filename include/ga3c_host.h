@@ -142,6 +142,16 @@ typedef int (*ga3c_predict_begin_fn)(void* net, const int64_t* offsets, int32_t 
 typedef int (*ga3c_predict_end_fn)(void* net, int32_t ticket, int32_t batch, float* p, float* v);
 int ga3c_pq_serve_pipelined(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga3c_predict_end_fn end, void* net, int32_t u8,
                             int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* stats);
+/* ... and for an engine that keeps the states it reads (ga3c_net_state_cache_config, include/ga3c_abi.h): `begin` has the
+ * signature of ga3c_net_predict_gather_begin_cached and also gets each row's name -- the agent's id and the number of the
+ * request that carried the state.  ga3c_pq_request_seq: that number for the agent's newest request (in flight, or answered
+ * last), which is how an agent names the state of an experience instead of shipping it (rollout rows of 16 bytes: request
+ * number i64, agent id i32; ga3c_tq_collect's row_seq / row_agent). */
+typedef int (*ga3c_predict_begin_cached_fn)(void* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs,
+                                            int32_t batch, int32_t u8, int32_t* ticket);
+int ga3c_pq_serve_pipelined_cached(ga3c_shm* shm, ga3c_predict_begin_cached_fn begin, ga3c_predict_end_fn end, void* net,
+                                   int32_t u8, int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* stats);
+int ga3c_pq_request_seq(ga3c_shm* shm, int32_t agent, int64_t* seq);
 /* The same loop for raw-frame requests (ga3c_pq_submit_flags): `serve` has the signature of ga3c_net_serve_frames
  * (include/ga3c_abi.h) and gets the popped slots' offsets, agent ids and request flags; stats->served counts the
  * predictions made (requests without GA3C_REQ_NO_PREDICT). */

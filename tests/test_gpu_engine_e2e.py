@@ -9,12 +9,16 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.timeout(180)
 @pytest.mark.filterwarnings("error::pytest.PytestUnhandledThreadExceptionWarning")
-@pytest.mark.parametrize("zero_copy", [True, False])
-def test_engine_trains_on_gpu(tmp_path, monkeypatch, zero_copy):
+@pytest.mark.parametrize("zero_copy,state_cache", [(True, True), (True, False), (False, False)])
+def test_engine_trains_on_gpu(tmp_path, monkeypatch, zero_copy, state_cache):
+    """state_cache: rollouts name their states (agent, request number) and the engine trains on the copies its
+    predictions kept in HBM (Config.STATE_CACHE, the default); off: the rollouts carry the states, read out of the
+    transport by the GPU (zero_copy) or copied by the trainer threads."""
     import ga3c_amd  # noqa: F401
     from Config import Config
     monkeypatch.chdir(tmp_path)
     monkeypatch.setattr(Config, "ZERO_COPY", zero_copy)
+    monkeypatch.setattr(Config, "STATE_CACHE", state_cache)
     saved = {k: getattr(Config, k) for k in ("AGENTS", "PREDICTORS", "TRAINERS", "SYNTHETIC_EPISODE_LENGTH", "TIME_MAX",
                                              "DYNAMIC_SETTINGS", "SAVE_MODELS", "TRAINING_MIN_BATCH_SIZE", "NUM_ACTIONS",
                                              "PREDICTION_BATCH_SIZE")}
@@ -25,7 +29,7 @@ def test_engine_trains_on_gpu(tmp_path, monkeypatch, zero_copy):
     try:
         from Server import Server
         srv = Server(max_agents=8)
-        assert srv.zero_copy == zero_copy
+        assert srv.zero_copy == zero_copy and srv.state_cache == state_cache
         before = srv.model.get_arena(0)
         srv.main(max_seconds=5)
         after = srv.model.get_arena(0)
@@ -149,6 +153,80 @@ def test_alternate_launch_paths_of_a_gathered_step_give_the_same_bits(monkeypatc
                 net.close()
         assert all(np.array_equal(p, q) for p, q in zip(outs[0], outs[1]))
     finally:
+        t.shutdown()
+        t.close()
+
+
+def test_state_cache_keeps_what_predictions_read_and_trains_on_it_by_name():
+    """ga3c_net_predict_gather_begin_cached stores the uint8 state of every row it reads in HBM (ring of `depth` per agent,
+    slot = request number % depth); ga3c_net_train_cached / evaluate_cached on rows NAMED (agent, request number) must be
+    ga3c_net_train_gather / evaluate on the same bytes, bit for bit; a name that was never stored, or has been overwritten,
+    is refused."""
+    import ga3c_amd  # noqa: F401
+    import _native as nat
+    import Transport as tp
+    from NetworkVP import Network
+    C = nat.C
+    t = tp.Transport.create(tp.unique_name("t_cache"), 40, 6, 84 * 84 * 4, 8, 8)
+    net = Network("gpu:0", "cache", 6, (84, 84, 4), max_batch=64, predict_lanes=2)
+    ref = Network("gpu:0", "cache_ref", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
+    depth = 4
+    try:
+        net.register_transport(t)                          # (ref gets the same bytes through the host-buffer entry points:
+        for n in (net, ref):                                # bit-identical to the zero-copy ones, tested above)
+            n.learning_rate, n.beta = 3e-4, 0.01
+        net.state_cache_config(40, depth)
+        rng = np.random.default_rng(31)
+        kept = {}                                           # (agent, request number) -> the bytes that were predicted on
+
+        def predict_named(ids, seqs):
+            offs = np.ascontiguousarray(t.state_offsets(ids), dtype=np.int64)
+            ag = np.ascontiguousarray(ids, dtype=np.int32)
+            sq = np.ascontiguousarray(seqs, dtype=np.int64)
+            ticket = C.c_int32(-1)
+            nat.check(net._lib.ga3c_net_predict_gather_begin_cached(net._h, nat.ptr(offs, nat.i64p), nat.ptr(ag, nat.i32p),
+                                                                    nat.ptr(sq, nat.i64p), ids.size, 1, C.byref(ticket)), "begin_cached")
+            p, v = np.empty((ids.size, 6), np.float32), np.empty(ids.size, np.float32)
+            nat.check(net._lib.ga3c_net_predict_gather_end(net._h, ticket.value, ids.size, nat.ptr(p), nat.ptr(v)), "end")
+            return p, v
+
+        for step in range(3):                               # three requests per agent, ragged batches
+            t.agent_states[:] = rng.integers(0, 256, size=(40, 84 * 84 * 4), dtype=np.uint8)
+            for ids in (np.arange(0, 17, dtype=np.uint32), np.arange(17, 40, dtype=np.uint32)):
+                seqs = 10 + step + ids.astype(np.int64) * 3
+                p, v = predict_named(ids, seqs)
+                want = ref.predict_p_and_v(t.agent_states[ids].reshape(-1, 84, 84, 4))
+                assert np.array_equal(p, want[0]) and np.array_equal(v, want[1])
+                for i, s_ in zip(ids, seqs):
+                    kept[(int(i), int(s_))] = t.agent_states[int(i)].copy()
+        # a train batch of 26 named rows against the same bytes put into rollout slots of the transport
+        names = [(a_, 10 + st + a_ * 3) for a_ in (3, 39, 17, 0, 21) for st in (0, 1, 2)] + [(a_, 12 + a_ * 3) for a_ in range(5, 16)]
+        agents = np.array([n_[0] for n_ in names], np.int32)
+        seqs = np.array([n_[1] for n_ in names], np.int64)
+        rows = len(names)
+        y = rng.uniform(-1, 1, rows)
+        a = np.eye(6, dtype=np.float32)[rng.integers(0, 6, rows)]
+        xs = np.stack([kept[key] for key in names]).reshape(-1, 84, 84, 4)
+        ev_named = net.evaluate(None, y, a, frames=(agents, seqs))
+        ev_rows = ref.evaluate(xs, y, a)
+        assert all(np.array_equal(p_, q_) for p_, q_ in zip(ev_named, ev_rows))
+        net.train_frames(agents, seqs, y, a)
+        ref.train(xs, y, a)
+        assert np.array_equal(net.get_arena(0), ref.get_arena(0)) and np.array_equal(net.get_arena(1), ref.get_arena(1))
+        # names the cache does not hold
+        with pytest.raises(RuntimeError):
+            net.train_frames(np.array([3], np.int32), np.array([22], np.int64), y[:1], a[:1])        # newer than the newest stored (21)
+        with pytest.raises(RuntimeError):
+            net.train_frames(np.array([40], np.int32), np.array([10], np.int64), y[:1], a[:1])       # no such agent
+        t.agent_states[:] = rng.integers(0, 256, size=(40, 84 * 84 * 4), dtype=np.uint8)
+        net.train_frames(np.array([3], np.int32), np.array([19], np.int64), y[:1], a[:1])            # agent 3 holds 19, 20, 21
+        predict_named(np.array([3], np.uint32), np.array([19 + depth], np.int64))                     # ... until request 23 takes 19's slot
+        with pytest.raises(RuntimeError):
+            net.train_frames(np.array([3], np.int32), np.array([19], np.int64), y[:1], a[:1])
+        net.train_frames(np.array([3], np.int32), np.array([19 + depth], np.int64), y[:1], a[:1])
+    finally:
+        net.close()
+        ref.close()
         t.shutdown()
         t.close()
 

@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
   auto fwd = [&](hipStream_t s) {
     hipLaunchKernelGGL((conv_stack_fwd_kernel<true, false>), dim3(B * 2), dim3(1024), lds_f, s, (const void*)x, pk + PK_W1F, th + OFF_B1,
-                       pk + PK_W2F, th + OFF_B2, n1, n2, B, (const int64_t*)nullptr, SrcOffsets{}); };
+                       pk + PK_W2F, th + OFF_B2, n1, n2, B, (const int64_t*)nullptr, SrcOffsets{}, (uint8_t*)nullptr); };
   auto bwd = [&](hipStream_t s) {
     hipLaunchKernelGGL(conv_bwd_kernel<false>, dim3(B * 2), dim3(1024), lds_b, s, (const void*)x, n1, dn2, pk + PK_W2DX, (float*)nullptr,
                        slab2, slab1, B, (const float*)nullptr, FusedUpd{}); };

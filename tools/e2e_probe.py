@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--linger-us", type=int, default=0)
     ap.add_argument("--linger-batch", type=int, default=0)
     ap.add_argument("--dynamic", action="store_true", help="ThreadDynamicAdjustment random walk every 2 s (soak test)")
+    ap.add_argument("--state-cache", type=int, default=-1, help="Config.STATE_CACHE (0 / 1; default: the package's)")
     ap.add_argument("--lanes", type=int, default=0, help="prediction lanes of the Network (0: one per predictor, the default)")
     ap.add_argument("--frames", choices=["planes", "planes-device", "rgb-host", "rgb-device"], default="planes",
                     help="frame source / where the reference's front-end runs (Config.FRAME_SOURCE, Config.FRONTEND)")
@@ -50,6 +51,8 @@ def main():
     Config.PREDICTION_LINGER_US, Config.PREDICTION_LINGER_BATCH = args.linger_us, args.linger_batch
     Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
     Config.TRAIN_MODELS = not args.no_train
+    if args.state_cache >= 0:
+        Config.STATE_CACHE = bool(args.state_cache)
     Config.HOGWILD = bool(args.hogwild)
     Config.NATIVE_PREDICTOR = not args.python_predictor
     if args.frames == "planes-device":
@@ -117,7 +120,7 @@ def main():
               "train_reader_waits_per_call": round(eng.get("train_reader_waits", 0) / tc, 3),
               "train_rows_per_call": round(eng.get("train_rows", 0) / tc, 1)}
     print(json.dumps({
-        "lanes": args.lanes or args.predictors, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "engine": engine,
+        "state_cache": bool(getattr(srv, "state_cache", False)), "lanes": args.lanes or args.predictors, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "engine": engine,
         "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / (b["t"] - a["t"]), 2), "throttled_periods": b["cg"][1] - a["cg"][1],
                    "throttled_s": round((b["cg"][2] - a["cg"][2]) / 1e6, 2)},
         "agents": args.agents, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,

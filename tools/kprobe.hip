@@ -36,8 +36,8 @@ int main(int argc, char** argv) {
   for (int u8 = 0; u8 < 2; ++u8) {
     for (int it = 0; it < 4; ++it) {
       CK(hipMemsetAsync(sb, 0, (size_t)nwg * 16 * 16 * 8, st));
-      if (u8) hipLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(nwg), dim3(1024), lds, st, (const void*)xu8, w, w + 4096, w + 8192, w + 20000, n1, n2, B, (const int64_t*)nullptr, SrcOffsets{});
-      else hipLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(nwg), dim3(1024), lds, st, (const void*)x, w, w + 4096, w + 8192, w + 20000, n1, n2, B, (const int64_t*)nullptr, SrcOffsets{});
+      if (u8) hipLaunchKernelGGL((conv_stack_fwd_kernel<false, true>), dim3(nwg), dim3(1024), lds, st, (const void*)xu8, w, w + 4096, w + 8192, w + 20000, n1, n2, B, (const int64_t*)nullptr, SrcOffsets{}, (uint8_t*)nullptr);
+      else hipLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(nwg), dim3(1024), lds, st, (const void*)x, w, w + 4096, w + 8192, w + 20000, n1, n2, B, (const int64_t*)nullptr, SrcOffsets{}, (uint8_t*)nullptr);
       CK(hipStreamSynchronize(st));
     }
     std::vector<unsigned long long> h((size_t)nwg * 16 * 16);
