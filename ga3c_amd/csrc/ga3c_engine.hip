@@ -1138,8 +1138,10 @@ struct ResidentHold {
 // calling thread owns that intake for the whole call); then, in the lane's turn, `body` runs with the intake bound to the
 // lane and the train stream ordered behind the staging.  While one thread is inside `body` (a step in flight), the next
 // thread's `stage` -- the PCIe gather of its rows -- proceeds on the staging stream.
+// in_line: the staging is HBM to HBM and short (rows out of the state cache): it goes on the TRAIN stream itself, in front of
+// the step -- beside a step, on the staging stream, even a 10-us copy stretched the step's kernels (conv2_dw 9 -> 43 us).
 template <class StageFn, class BodyFn, class DoneFn>
-int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body, DoneFn&& done) {
+int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body, DoneFn&& done, bool in_line = false) {
   if (B < 1 || B > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", B, net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
   TrainLane* t = pick_train_lane(net);
@@ -1149,9 +1151,10 @@ int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body, Done
   Intake* in = take_intake(*t);
   std::lock_guard<std::mutex> ig(in->mu, std::adopt_lock);
   Stage s = intake_stage(*t, *in);
+  if (in_line) s.st = t->st;
   CHK(stage(s));
   in->x_u8 = s.x_u8;
-  HIPCHK(hipEventRecord(in->ready, t->gst));
+  if (!in_line) HIPCHK(hipEventRecord(in->ready, t->gst));
   stage_range.pop();
   const int64_t t1 = now_ns();
   {
@@ -1163,7 +1166,7 @@ int with_staged_batch(ga3c_net* net, int B, StageFn&& stage, BodyFn&& body, Done
     std::lock_guard<std::mutex> tl(t->mu, std::adopt_lock);
     const int64_t t2 = now_ns();
     bind_intake(*t, *in);
-    HIPCHK(hipStreamWaitEvent(t->st, in->ready, 0));
+    if (!in_line) HIPCHK(hipStreamWaitEvent(t->st, in->ready, 0));
     stat_add(net, GA3C_STAT_TRAIN_STAGE_NS, t1 - t0);
     stat_add(net, GA3C_STAT_TRAIN_LANE_WAIT_NS, t2 - t1);
     CHK(body(*t, *in));
@@ -2113,7 +2116,7 @@ int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth
 // rows named (agent, request number) -> the intake's uint8 rows, HBM to HBM; returns / actions as for any staged batch
 static int stage_cached_rows(ga3c_net* net, Stage& s, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                              int32_t batch) {
-  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
+  if (batch < 1 || batch > net->maxB || batch > 192) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB < 192 ? net->maxB : 192);
   CHK(cache_offsets(net, agents, seqs, batch, false, s.h_off));
   float* hy = s.h_in + (size_t)net->maxB * XS;
   float* ha = hy + net->maxB;
@@ -2121,10 +2124,10 @@ static int stage_cached_rows(ga3c_net* net, Stage& s, const int32_t* agents, con
   if (y_r) { memcpy(hy, y_r, (size_t)batch * sizeof(float)); sc.src0 = hy; sc.dst0 = s.yr; sc.n0 = batch; }
   if (a) { memcpy(ha, a, (size_t)batch * net->A * sizeof(float)); sc.src1 = ha; sc.dst1 = s.act; sc.n1 = batch * net->A; }
   RowOffsets ro;
-  ro.n = 0;
-  if (batch <= 192) { memcpy(ro.off, s.h_off, (size_t)batch * sizeof(int64_t)); ro.n = batch; }
-  // (reads HBM, not the bus: wide is fine, and the rows are there in a few microseconds)
-  hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(batch, XS / 16, 256)), dim3(256), 0, s.st, net->cache_ring, s.h_off,
+  memcpy(ro.off, s.h_off, (size_t)batch * sizeof(int64_t));
+  ro.n = batch;
+  // (reads HBM, not the bus: a thread per 16 bytes, the rows are there in a few microseconds)
+  hipLaunchKernelGGL(copy_rows_kernel<XS / 16>, dim3((XS / 16 + 255) / 256, batch), dim3(256), 0, s.st, net->cache_ring,
                      reinterpret_cast<uint4*>(s.xu8), batch, sc, ro);
   HIPCHK(hipGetLastError());
   s.x_u8 = true;
@@ -2136,7 +2139,7 @@ int ga3c_net_train_cached(ga3c_net* net, const int32_t* agents, const int64_t* s
   if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_cached_rows(net, s, agents, seqs, y_r, a, batch); },
                            [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
-                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
+                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); }, true);
 }
 
 int ga3c_net_evaluate_cached(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
@@ -2144,7 +2147,7 @@ int ga3c_net_evaluate_cached(ga3c_net* net, const int32_t* agents, const int64_t
   if (!net || !agents || !seqs || !y_r || !a) return fail(GA3C_EINVAL, "null argument");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_cached_rows(net, s, agents, seqs, y_r, a, batch); },
                            [&](TrainLane& t, Intake&) { return evaluate_staged(net, t, batch, beta, losses, d1, v, p); },
-                           [](TrainLane&, Intake&) { return (int)GA3C_OK; });
+                           [](TrainLane&, Intake&) { return (int)GA3C_OK; }, true);
 }
 
 int ga3c_net_frames_pushed(ga3c_net* net, int32_t agent, int64_t* pushed) {
