@@ -278,6 +278,7 @@ struct ga3c_net {
   int cache_agents = 0, cache_depth = 0;
   std::mutex cache_mu;
   std::vector<int64_t> cache_newest;   // per agent: the newest request number stored (-1: none)
+  bool frames_in_line = true;          // GA3C_FRAMES_IN_LINE=0: rows out of the plane history are staged on the staging stream, beside a step
   bool stop_events = true;             // GA3C_STOP_EVENTS=0: a prediction step's completion event is a hipEventRecord of its own
   bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
   bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
@@ -1398,6 +1399,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
   if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
   if (const char* e = getenv("GA3C_STOP_EVENTS")) net->stop_events = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_FRAMES_IN_LINE")) net->frames_in_line = atoi(e) != 0;
   if (const char* e = getenv("GA3C_FUSED_UPDATE")) net->fused_update = atoi(e) != 0;
   if (const char* e = getenv("GA3C_GATHER_BLOCKS")) net->gather_max_blocks = atoi(e) > 0 ? atoi(e) : 32;
   for (const void* fn : {reinterpret_cast<const void*>(&conv_bwd_kernel<true, false>), reinterpret_cast<const void*>(&conv_bwd_kernel<false, false>),
@@ -2080,7 +2082,7 @@ int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* s
   if (!net->fr.on || !net->fr.hist) return fail(GA3C_ESTATE, "frames: no plane history configured (ga3c_net_frames_config, history > 0)");
   return with_staged_batch(net, batch, [&](Stage& s) { return stage_history_rows(net, s, agents, seqs, y_r, a, batch); },
                            [&](TrainLane& t, Intake& in) { return train_enqueue(net, t, in, batch, learning_rate, beta); },
-                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); });
+                           [&](TrainLane&, Intake& in) { return train_finish(net, in, losses); }, net->frames_in_line);
 }
 
 int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,

@@ -625,6 +625,55 @@ def test_pipelined_serve_loop_batches_routes_and_overlaps(mods, golden_dir, key,
         t.close()
 
 
+def test_cached_serve_loop_names_every_row_by_agent_and_request_number(mods):
+    """ga3c_pq_serve_pipelined_cached hands the engine, per row, the agent's id and the number of the request that carries the
+    state (ga3c_pq_request_seq): what the engine's state cache files the state under and what the agent's experience will
+    name.  Numbers count an agent's submits, one by one, from wherever the slot's counter stands."""
+    import ctypes as C
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_named"), 6, 6, 64, 4, 6)
+    seen, held = [], {}
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
+                 C.POINTER(C.c_int32))
+    def begin(net, offsets, agents, seqs, batch, u8, ticket):
+        rows = [(int(agents[i]), int(seqs[i]), int(offsets[i])) for i in range(batch)]
+        seen.extend(rows)
+        held[len(seen)] = rows
+        ticket[0] = len(seen)
+        return 0
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+    def end(net, ticket, batch, p, v):
+        for i, (ag, sq, _) in enumerate(held.pop(ticket)):
+            v[i] = float(sq)
+            for a in range(6):
+                p[i * 6 + a] = float(ag)
+        return 0
+
+    b, e = C.cast(begin, C.c_void_p).value, C.cast(end, C.c_void_p).value
+    try:
+        assert [t.request_seq(i) for i in range(6)] == [0] * 6
+        st = nat.ServeStats()
+        expect = []
+        for round_ in range(3):
+            ids = [0, 2, 5] if round_ != 1 else [2, 3]
+            for i in ids:
+                assert t.submit(i) == 0
+                expect.append((i, t.request_seq(i)))
+            while sum(1 for i in ids if not t.agent_idle(i)):
+                assert t.serve_pipelined_cached(b, e, None, 1, 8, 20, st) == 0
+            for i in ids:
+                rc, p, v = t.wait(i, 1000)
+                assert rc == 0 and v == float(t.request_seq(i)) and p.tolist() == [float(i)] * 6
+        assert sorted((ag, sq) for ag, sq, _ in seen) == sorted(expect)
+        assert [t.request_seq(i) for i in range(6)] == [2, 0, 3, 1, 0, 2]
+        assert all(off == t.state_offsets(np.array([ag], np.uint32))[0] for ag, _, off in seen)
+    finally:
+        t.shutdown()
+        t.close()
+
+
 def test_pipelined_serve_loop_reports_a_failing_engine_and_still_answers_what_it_holds(mods):
     import ctypes as C
     nat, tp, Config = mods

@@ -240,6 +240,83 @@ def test_trainers_cannot_starve_the_agents_of_rollout_slots(tmp_path, monkeypatc
     assert len(model.train_rows) <= spills <= len(model.train_rows) + 2
 
 
+class _StateCacheStandIn(_ZeroCopyStandIn):
+    """A stand-in with the state-cache entry points (Config.STATE_CACHE): its `begin` keeps the bytes of every state it is
+    handed under the row's name, its train_frames looks the named rows up -- and fails on a name it never saw or one that has
+    been overwritten in its ring of `depth` states per agent."""
+
+    def __init__(self, n_act):
+        super().__init__(n_act)
+        import ctypes as C
+        self.kept, self.depth, self.trained, self.errors, self.held = {}, None, [], [], {}
+        self.lock = __import__("threading").Lock()
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
+                     C.POINTER(C.c_int32))
+        def begin(net, offsets, agents, seqs, batch, u8, ticket):
+            raw = self.transport._raw
+            with self.lock:
+                for i in range(batch):
+                    ag, sq, off = int(agents[i]), int(seqs[i]), int(offsets[i])
+                    self.kept[(ag, sq % self.depth)] = (sq, bytes(raw[off:off + 64]))
+                self.held[id(ticket)] = batch
+            ticket[0] = 0
+            return 0
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+        def end(net, ticket, batch, p, v):
+            for i in range(batch):
+                v[i] = 0.0
+                for a in range(self.n_act):
+                    p[i * self.n_act + a] = 1.0 / self.n_act
+            return 0
+        self._begin, self._end, self._C = begin, end, C
+
+    def state_cache_config(self, max_agents, depth):
+        self.depth = int(depth)
+
+    def gather_entry(self):
+        return None, None, 1
+
+    def gather_entries_pipelined(self):
+        return None
+
+    def gather_entries_pipelined_cached(self):
+        C = self._C
+        return C.cast(self._begin, C.c_void_p).value, C.cast(self._end, C.c_void_p).value, None, 1
+
+    def train_frames(self, agents, seqs, y_r, a):
+        with self.lock:
+            for ag, sq in zip(agents.tolist(), seqs.tolist()):
+                got = self.kept.get((ag, sq % self.depth))
+                if got is None or got[0] != sq:
+                    self.errors.append((ag, sq, None if got is None else got[0]))
+            self.trained.append(len(agents))
+
+
+@pytest.mark.timeout(120)
+def test_state_cache_protocol_on_cpu(tmp_path, monkeypatch):
+    """Config.STATE_CACHE with a stand-in engine: the agents name the states of their experiences by request number, the native
+    predictor loop hands every row's name to the engine, the native batch assembly collects names instead of states, and every
+    name a trainer asks for is one the engine was given -- and still holds in a ring of the depth the Server computed."""
+    import ga3c_amd  # noqa: F401
+    from Config import Config
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(AGENTS=5, PREDICTORS=2, TRAINERS=2, SYNTHETIC_EPISODE_LENGTH=40, TIME_MAX=5, DYNAMIC_SETTINGS=False,
+                     SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=17, NUM_ACTIONS=6, ZERO_COPY=True, STATE_CACHE=True,
+                     PREDICTION_BATCH_SIZE=32).items():
+        monkeypatch.setattr(Config, k, v)
+    from Server import Server
+    model = _StateCacheStandIn(6)
+    srv = Server(model=model, max_agents=8)
+    assert srv.state_cache and srv.zero_copy and model.depth and srv.transport.row_bytes == 16
+    srv.main(max_seconds=5)
+    monkeypatch.setattr(Config, "STATE_CACHE_ACTIVE", False)
+    assert len(model.trained) >= 5 and min(model.trained) >= 18 and srv.training_step == len(model.trained)
+    assert not model.errors, model.errors[:5]
+    assert len(model.kept) > 50 and not model.train_rows and not model.offset_batches    # no state ever travelled in a rollout
+
+
 @pytest.mark.timeout(60)
 def test_a_run_that_ends_at_once_shuts_down_cleanly(tmp_path, monkeypatch):
     """EPISODES already reached (e.g. _play.sh on a checkpoint from a later episode): the main loop ends while the
