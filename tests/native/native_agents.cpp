@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -31,7 +32,11 @@ int main(int argc, char** argv) {
   if (n > cfg.max_agents) { fprintf(stderr, "segment does not fit (%d agents max)\n", cfg.max_agents); return 1; }
   // rollout_row_bytes == 16: the frame queue lives on the device (Config.FRONTEND = 'device'): the slot carries the newest
   // frame / plane, requests carry flags, rollout rows name their state as (plane sequence number, agent id)
-  const bool device = cfg.rollout_row_bytes == 16;
+  // ... or, with "cache" as the fifth argument, the engine's state cache is in use (Config.STATE_CACHE): the slot carries the
+  // whole state as ever, rollout rows name it as (request number, agent id)
+  const bool cache = argc > 5 && std::string(argv[5]) == "cache";
+  if (cache && cfg.rollout_row_bytes != 16) { fprintf(stderr, "\"cache\" needs 16-byte rollout rows\n"); return 1; }
+  const bool device = cfg.rollout_row_bytes == 16 && !cache;
   const size_t sb = (size_t)cfg.state_bytes;
   std::vector<unsigned char> pool(64 * sb);
   std::mt19937_64 rng(12345);
@@ -77,6 +82,7 @@ int main(int argc, char** argv) {
         int a = cfg.num_actions - 1;
         for (int i = 0; i < cfg.num_actions; ++i) { c += p[i]; if (u < c) { a = i; break; } }
         acts[t] = a; frames[t] = k; seqs[t] = pushed - 1;
+        if (cache) { int64_t rq = 0; ga3c_pq_request_seq(shm, id, &rq); seqs[t] = rq; }
         ++mine;
         if (++t == cfg.train_rows - 1) {                        // TIME_MAX steps: ship the rollout
           if (train) {
@@ -88,7 +94,7 @@ int main(int argc, char** argv) {
             float* ret = ga3c_tq_returns(shm, s);
             int32_t* ac = ga3c_tq_actions(shm, s);
             for (int i = 0; i < t; ++i) {
-              if (device) { memcpy(st + (size_t)i * 16, &seqs[i], 8); const int32_t me = id; memcpy(st + (size_t)i * 16 + 8, &me, 4); }
+              if (device || cache) { memcpy(st + (size_t)i * 16, &seqs[i], 8); const int32_t me = id; memcpy(st + (size_t)i * 16 + 8, &me, 4); }
               else memcpy(st + (size_t)i * sb, &pool[(size_t)frames[i] * sb], sb);
               ret[i] = 0.01f * (float)(i - 2); ac[i] = acts[i];
             }

@@ -451,7 +451,8 @@ def test_engine_at_the_agent_counts_of_baseline_configs_3_and_4(tmp_path, monkey
 
         def driver():
             time.sleep(1.0)
-            proc = subprocess.Popen([exe, srv.transport.name, str(agents), str(seconds - 2.5), "1"], stdout=subprocess.PIPE, text=True)
+            proc = subprocess.Popen([exe, srv.transport.name, str(agents), str(seconds - 2.5), "1"] + (["cache"] if srv.state_cache else []),
+                                    stdout=subprocess.PIPE, text=True)
             for at in (3.0, seconds - 2.0):
                 time.sleep(max(0.0, at - (time.perf_counter() - t0)))
                 marks.append((time.perf_counter(), srv.predictions_served, srv.training_step, sum(p.batches for p in srv.predictors)))

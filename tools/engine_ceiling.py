@@ -82,7 +82,8 @@ def main():
 
     def driver():
         time.sleep(1.0)                                   # predictors and trainers are up
-        proc = subprocess.Popen([exe, srv.transport.name, str(args.agents), str(args.seconds - 2.0), "0" if args.no_train else "1"],
+        proc = subprocess.Popen([exe, srv.transport.name, str(args.agents), str(args.seconds - 2.0), "0" if args.no_train else "1"] +
+                                (["cache"] if getattr(srv, "state_cache", False) else []),
                                 stdout=subprocess.PIPE, text=True)
         time.sleep(args.warm)
         snap["a"] = take()
