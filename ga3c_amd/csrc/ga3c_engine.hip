@@ -692,9 +692,16 @@ int claim_other_buffer(ga3c_net* net, TrainLane& t, int* idx_out, int* other_out
   const int other = c == idx ? (idx + 1) % 3 : 3 - idx - c;
   for (Lane* L : net->lanes) {
     if (L->dirty[other]) {
-      HIPCHK(hipStreamWaitEvent(t.st, L->done, 0));    // the lane's last step (at least as late as its last read of `other`)
+      // the lane's last step is at least as late as its last read of `other`: if it has finished (the usual case -- the
+      // buffer was `cur` two steps ago) there is nothing to order; a wait costs the host a call and the train stream a
+      // barrier packet (several microseconds of queue idle each on this stack)
+      const hipError_t q = hipEventQuery(L->done);
+      if (q != hipSuccess) {
+        (void)hipGetLastError();                           // hipErrorNotReady is not an error here
+        HIPCHK(hipStreamWaitEvent(t.st, L->done, 0));
+        stat_add(net, GA3C_STAT_TRAIN_READER_WAITS, 1);
+      }
       L->dirty[other] = false;
-      stat_add(net, GA3C_STAT_TRAIN_READER_WAITS, 1);
     }
   }
   // From here until the step is published the buffer holds no weights anyone may adopt: it may be the in-between buffer of
