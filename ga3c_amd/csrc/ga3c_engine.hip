@@ -2125,7 +2125,7 @@ int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth
 // rows named (agent, request number) -> the intake's uint8 rows, HBM to HBM; returns / actions as for any staged batch
 static int stage_cached_rows(ga3c_net* net, Stage& s, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                              int32_t batch) {
-  if (batch < 1 || batch > net->maxB || batch > 192) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB < 192 ? net->maxB : 192);
+  if (batch < 1 || batch > net->maxB) return fail(GA3C_EINVAL, "batch %d outside [1,%d]", batch, net->maxB);
   CHK(cache_offsets(net, agents, seqs, batch, false, s.h_off));
   float* hy = s.h_in + (size_t)net->maxB * XS;
   float* ha = hy + net->maxB;
@@ -2133,10 +2133,10 @@ static int stage_cached_rows(ga3c_net* net, Stage& s, const int32_t* agents, con
   if (y_r) { memcpy(hy, y_r, (size_t)batch * sizeof(float)); sc.src0 = hy; sc.dst0 = s.yr; sc.n0 = batch; }
   if (a) { memcpy(ha, a, (size_t)batch * net->A * sizeof(float)); sc.src1 = ha; sc.dst1 = s.act; sc.n1 = batch * net->A; }
   RowOffsets ro;
-  memcpy(ro.off, s.h_off, (size_t)batch * sizeof(int64_t));
-  ro.n = batch;
+  ro.n = 0;
+  if (batch <= 192) { memcpy(ro.off, s.h_off, (size_t)batch * sizeof(int64_t)); ro.n = batch; }
   // (reads HBM, not the bus: a thread per 16 bytes, the rows are there in a few microseconds)
-  hipLaunchKernelGGL(copy_rows_kernel<XS / 16>, dim3((XS / 16 + 255) / 256, batch), dim3(256), 0, s.st, net->cache_ring,
+  hipLaunchKernelGGL(copy_rows_kernel<XS / 16>, dim3((XS / 16 + 255) / 256, batch), dim3(256), 0, s.st, net->cache_ring, s.h_off,
                      reinterpret_cast<uint4*>(s.xu8), batch, sc, ro);
   HIPCHK(hipGetLastError());
   s.x_u8 = true;

@@ -190,14 +190,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restr
 // Rows of a batch copied out of the state cache (HBM to HBM): workgroup = (256-chunk piece, row); the row's offset comes out
 // of the kernel arguments.  (gather_rows_kernel, built to wait on the bus with few waves, needed 50-60 us for these 3.7 MB.)
 template <int CHUNKS>
-__global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ base, uint4* __restrict__ dst, int B,
-                                                        SmallCopy sc, const RowOffsets ro) {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ base, const int64_t* __restrict__ offsets,
+                                                        uint4* __restrict__ dst, int B, SmallCopy sc, const RowOffsets ro) {
   const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == 0 && b == 0) {
     for (int i = threadIdx.x; i < sc.n0; i += 256) sc.dst0[i] = sc.src0[i];
     for (int i = threadIdx.x; i < sc.n1; i += 256) sc.dst1[i] = sc.src1[i];
   }
-  if (b < B && c < CHUNKS) dst[(size_t)b * CHUNKS + c] = *reinterpret_cast<const uint4*>(base + ro.off[b] + (size_t)c * 16);
+  // (batches beyond the 192 offsets that fit the arguments read them out of the pinned array: ro.n == 0)
+  if (b < B && c < CHUNKS) dst[(size_t)b * CHUNKS + c] = *reinterpret_cast<const uint4*>(base + (ro.n ? ro.off[b < 192 ? b : 0] : offsets[b]) + (size_t)c * 16);
 }
 
 // ------------------------------------------------------------------ conv1 forward

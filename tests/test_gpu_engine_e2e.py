@@ -219,6 +219,33 @@ def test_state_cache_keeps_what_predictions_read_and_trains_on_it_by_name():
         with pytest.raises(RuntimeError):
             net.train_frames(np.array([40], np.int32), np.array([10], np.int64), y[:1], a[:1])       # no such agent
         t.agent_states[:] = rng.integers(0, 256, size=(40, 84 * 84 * 4), dtype=np.uint8)
+        # a batch beyond the 192 offsets that travel in the kernel arguments (they are then read out of the pinned array)
+        big = Network("gpu:0", "cache_big", 6, (84, 84, 4), max_batch=256, predict_lanes=1)
+        bref = Network("gpu:0", "cache_bigref", 6, (84, 84, 4), max_batch=256, predict_lanes=1)
+        net.unregister_transport()                          # (one registration of the segment at a time)
+        try:
+            big.register_transport(t)
+            big.state_cache_config(40, depth)
+            for n in (big, bref):
+                n.learning_rate, n.beta = 3e-4, 0.01
+            ids40 = np.arange(40, dtype=np.uint32)
+            offs40 = np.ascontiguousarray(t.state_offsets(ids40), dtype=np.int64)
+            tk = C.c_int32()
+            p40, v40 = np.empty((40, 6), np.float32), np.empty(40, np.float32)
+            nat.check(big._lib.ga3c_net_predict_gather_begin_cached(big._h, nat.ptr(offs40, nat.i64p), nat.ptr(ids40.astype(np.int32), nat.i32p),
+                                                                    nat.ptr(np.full(40, 7, np.int64), nat.i64p), 40, 1, C.byref(tk)), "begin_cached")
+            nat.check(big._lib.ga3c_net_predict_gather_end(big._h, tk.value, 40, nat.ptr(p40), nat.ptr(v40)), "end")
+            ag200 = (np.arange(200) % 40).astype(np.int32)
+            y200 = rng.uniform(-1, 1, 200)
+            a200 = np.eye(6, dtype=np.float32)[rng.integers(0, 6, 200)]
+            big.train_frames(ag200, np.full(200, 7, np.int64), y200, a200)
+            bref.train(t.agent_states[ag200].reshape(-1, 84, 84, 4), y200, a200)
+            assert np.array_equal(big.get_arena(0), bref.get_arena(0))
+        finally:
+            big.unregister_transport()
+            big.close()
+            bref.close()
+            net.register_transport(t)
         net.train_frames(np.array([3], np.int32), np.array([19], np.int64), y[:1], a[:1])            # agent 3 holds 19, 20, 21
         predict_named(np.array([3], np.uint32), np.array([19 + depth], np.int64))                     # ... until request 23 takes 19's slot
         with pytest.raises(RuntimeError):
