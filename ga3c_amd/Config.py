@@ -86,7 +86,7 @@ class Config:
     STATE_CACHE = True                  # the engine keeps the uint8 states its predictions read (a ring per agent in HBM) and
                                         # rollouts NAME their states (agent, request number) instead of carrying them: no second
                                         # trip over PCIe for training (needs ZERO_COPY, STATE_TRANSPORT = 'u8', the native
-                                        # pipelined predictor, PREDICTION_BATCH_SIZE <= 128; Server falls back without them)
+                                        # pipelined predictor and trainer loops; Server falls back without them)
     STATE_CACHE_ACTIVE = False          # (set by Server for its agents: the cache is really in use)
     NATIVE_TRAINER = True               # ThreadTrainer's batch assembly in one native call (ga3c_tq_collect) when ZERO_COPY is on
     PREDICTION_LINGER_US = 0            # > 0: a predictor holding fewer than PREDICTION_LINGER_BATCH requests after its

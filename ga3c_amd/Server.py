@@ -48,12 +48,12 @@ class Server:
         # State cache: the engine keeps the uint8 states its predictions read and rollouts name them (agent, request number)
         # instead of carrying them -- a trainer's batch no longer crosses PCIe a second time (include/ga3c_abi.h).  Only with
         # everything it rests on: the GPU reading the transport itself, uint8 states, the native pipelined predictor loop,
-        # batches within the fused conv stack's range, plain launches; anything else keeps the states in the rollouts.
+        # plain launches; anything else keeps the states in the rollouts.
         model_cls = Network if model is None else type(model)
         self.state_cache = bool(getattr(Config, "STATE_CACHE", False) and not self.device_frontend and Config.ZERO_COPY and
                                 Config.STATE_TRANSPORT == 'u8' and getattr(Config, "NATIVE_PREDICTOR", True) and
                                 getattr(Config, "PIPELINED_PREDICTOR", True) and getattr(Config, "NATIVE_TRAINER", True) and
-                                Config.PREDICTION_BATCH_SIZE <= 128 and not os.environ.get("GA3C_GRAPHS") and
+                                not os.environ.get("GA3C_GRAPHS") and
                                 hasattr(model_cls, "state_cache_config") and hasattr(model_cls, "gather_entries_pipelined_cached"))
         Config.STATE_CACHE_ACTIVE = self.state_cache         # (the agents read it from their configuration snapshot)
         if self.state_cache:

@@ -102,7 +102,7 @@ struct Lane {
   bool shared_st = false;     // another lane enqueues on `st` too: completion is waited for on `done`, not on the stream
   int sidx = 0;               // which of the prediction streams `st` is (index into ga3c_net::stream_busy)
   std::atomic<bool> begun{false};   // taken by ga3c_net_predict_gather_begin, to be given back by _end
-  int64_t cache_dst[128];           // byte offsets into the state cache of the batch begun with _begin_cached
+  int64_t* cache_dst = nullptr;     // pinned [maxB]: byte offsets into the state cache of the batch begun with _begin_cached
   bool cache_on = false;
   hipEvent_t done = nullptr;
   hipEvent_t tm0 = nullptr, tm1 = nullptr;   // timing events of ga3c_net_time_predict_lanes
@@ -598,6 +598,9 @@ int launch_step(ga3c_net* net, Lane& L, int idx, int B, int mode, float* out_p, 
       ro.n = 0;                                              // (beyond the fused conv stack's range: batches of more than 128 rows)
       if (u8) hipLaunchKernelGGL(gather_rows_kernel<XS / 16>, dim3(gather_blocks(B, XS / 16, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.xu8), B, none, ro);
       else hipLaunchKernelGGL(gather_rows_kernel<XS / 4>, dim3(gather_blocks(B, XS / 4, net->gather_max_blocks)), dim3(256), 0, L.st, base, L.h_off, reinterpret_cast<uint4*>(L.f.x), B, none, ro);
+      if (L.cache_on && mode == STEP_GATHER_U8)               // ... and the state cache takes its copy from the gathered batch
+        hipLaunchKernelGGL(file_rows_kernel<XS / 16>, dim3((XS / 16 + 255) / 256, B), dim3(256), 0, L.st, reinterpret_cast<const uint4*>(L.f.xu8),
+                           net->cache_ring, L.cache_dst, B);
     }
   }
   const int rc = launch_forward(net, L.f, idx, B, L.st, false, nullptr, 0.f, out_p, out_v, stop_ev);
@@ -1520,6 +1523,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     TRYHIP(hipHostMalloc((void**)&L->h_in, (size_t)maxB * XS * sizeof(float), hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void**)&L->h_out, ((size_t)maxB * (2 * A + 1)) * sizeof(float), hipHostMallocDefault));
     TRYHIP(hipHostMalloc((void**)&L->h_off, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
+    TRYHIP(hipHostMalloc((void**)&L->cache_dst, (size_t)maxB * sizeof(int64_t), hipHostMallocDefault));
   }
   TRY(alloc_train_lane(net, net->tr, net->grad));
   net->hogwild = cfg->train_lanes >= 2;
@@ -1552,6 +1556,7 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (L->h_in) (void)hipHostFree(L->h_in);
     if (L->h_out) (void)hipHostFree(L->h_out);
     if (L->h_off) (void)hipHostFree(L->h_off);
+    if (L->cache_dst) (void)hipHostFree(L->cache_dst);
     for (hipEvent_t e : {L->done, L->tm0, L->tm1})
       if (e) (void)hipEventDestroy(e);
     if (L->st && L->owns_st) (void)hipStreamDestroy(L->st);
@@ -1768,8 +1773,8 @@ static int predict_begin_common(ga3c_net* net, const int64_t* offsets, const int
   HIPCHK(hipSetDevice(net->cfg.device));
   if (agents) {
     if (!seqs) return fail(GA3C_EINVAL, "null argument");
-    if (!u8 || net->graphs || !net->fused_conv || batch > FUSED_CONV_MAX_B || batch > 128)
-      return fail(GA3C_ESTATE, "the state cache is filled by plain launches of the fused conv stack on uint8 states (batch <= 128)");
+    if (!u8 || net->graphs)
+      return fail(GA3C_ESTATE, "the state cache is filled by plain launches on uint8 states");
   }
   Lane* L = take_lane(net);                                  // stays taken until ga3c_net_predict_gather_end
   net->predict_inflight.fetch_add(1, std::memory_order_relaxed);

@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restric
   if (b < B && c < CHUNKS) dst[(size_t)b * CHUNKS + c] = *reinterpret_cast<const uint4*>(base + (ro.n ? ro.off[b < 192 ? b : 0] : offsets[b]) + (size_t)c * 16);
 }
 
+// ... and the other way: the dense uint8 rows of a batch (gathered for a prediction step beyond the fused conv stack's 128 rows)
+// filed into the state cache, row b at base + dst_off[b] (offsets in a pinned array)
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void file_rows_kernel(const uint4* __restrict__ src, uint8_t* __restrict__ base,
+                                                        const int64_t* __restrict__ dst_off, int B) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (b < B && c < CHUNKS) *reinterpret_cast<uint4*>(base + dst_off[b] + (size_t)c * 16) = src[(size_t)b * CHUNKS + c];
+}
+
 // ------------------------------------------------------------------ conv1 forward
 // n1[m][o] = relu(b1[o] + sum_k patch(m)[k] W1[k][o]),  m = (b*21+i)*21+j, k = (u*8+v)*4+c.
 // Implicit GEMM M = B*441, K = 256, N = 16.  im2col re-reads every input pixel 4x; served from L2 that

@@ -162,7 +162,8 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
  * names its rows the same way (ProcessAgent.py:88-100 ships the state itself; NetworkVP.py:254-257 feeds it) and is
  * gathered HBM to HBM: ga3c_net_train_cached / ga3c_net_evaluate_cached = ga3c_net_train_gather / ga3c_net_evaluate on
  * those rows, bit for bit.  A row whose request is not held (never stored, or more than `depth` requests of its agent
- * ago) is refused with GA3C_ESTATE.  uint8 states, plain launches of the fused conv stack (batch <= 128, no GA3C_GRAPHS). */
+ * ago) is refused with GA3C_ESTATE.  uint8 states, plain launches (no GA3C_GRAPHS): up to 128 rows the conv stack stores
+ * the bytes it stages, beyond that the gathered batch is filed by a copy kernel behind the gather. */
 int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth);
 int ga3c_net_predict_gather_begin_cached(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs,
                                          int32_t batch, int32_t u8, int32_t* ticket);

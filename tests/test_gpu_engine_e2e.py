@@ -241,6 +241,21 @@ def test_state_cache_keeps_what_predictions_read_and_trains_on_it_by_name():
             big.train_frames(ag200, np.full(200, 7, np.int64), y200, a200)
             bref.train(t.agent_states[ag200].reshape(-1, 84, 84, 4), y200, a200)
             assert np.array_equal(big.get_arena(0), bref.get_arena(0))
+            # ... and a PREDICTION batch beyond the fused conv stack's 128 rows: the gathered batch is filed into the cache by
+            # a copy kernel (here 160 rows: every agent four times, under four request numbers)
+            t.agent_states[:] = rng.integers(0, 256, size=(40, 84 * 84 * 4), dtype=np.uint8)
+            ids160 = (np.arange(160) % 40).astype(np.uint32)
+            sq160 = (8 + np.arange(160) // 40).astype(np.int64)
+            offs160 = np.ascontiguousarray(t.state_offsets(ids160), dtype=np.int64)
+            p160, v160 = np.empty((160, 6), np.float32), np.empty(160, np.float32)
+            nat.check(big._lib.ga3c_net_predict_gather_begin_cached(big._h, nat.ptr(offs160, nat.i64p), nat.ptr(ids160.astype(np.int32), nat.i32p),
+                                                                    nat.ptr(sq160, nat.i64p), 160, 1, C.byref(tk)), "begin_cached")
+            nat.check(big._lib.ga3c_net_predict_gather_end(big._h, tk.value, 160, nat.ptr(p160), nat.ptr(v160)), "end")
+            want160 = bref.predict_p_and_v(t.agent_states[ids160].reshape(-1, 84, 84, 4))
+            assert np.array_equal(p160, want160[0]) and np.array_equal(v160, want160[1])
+            big.train_frames(ids160[:100].astype(np.int32), np.full(100, 10, np.int64), y200[:100], a200[:100])   # every agent's request 10
+            bref.train(t.agent_states[ids160[:100]].reshape(-1, 84, 84, 4), y200[:100], a200[:100])
+            assert np.array_equal(big.get_arena(0), bref.get_arena(0))
         finally:
             big.unregister_transport()
             big.close()
