@@ -1021,36 +1021,57 @@ int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, i
   if (!shm || !serve || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
   Header* h = shm->hdr();
   const int A = h->cfg.num_actions;
-  std::vector<uint32_t> ids((size_t)max_batch), flags((size_t)max_batch);
+  // two sets of result buffers: the helper thread answers batch k out of one while batch k+1 is served into the other
+  std::vector<uint32_t> ids[2] = {std::vector<uint32_t>((size_t)max_batch), std::vector<uint32_t>((size_t)max_batch)};
+  std::vector<float> p[2] = {std::vector<float>((size_t)max_batch * A, 0.f), std::vector<float>((size_t)max_batch * A, 0.f)};
+  std::vector<float> v[2] = {std::vector<float>((size_t)max_batch, 0.f), std::vector<float>((size_t)max_batch, 0.f)};
+  std::vector<uint32_t> flags((size_t)max_batch);
   std::vector<int32_t> agents((size_t)max_batch);
   std::vector<int64_t> offs((size_t)max_batch);
-  std::vector<float> p((size_t)max_batch * A, 0.f), v((size_t)max_batch, 0.f);
   const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
+  const char* he = getenv("GA3C_RESPONDER");
+  const bool use_helper = !he || atoi(he) != 0;
+  Responder helper;
+  if (use_helper) {
+    helper.shm = shm;
+    if (const char* e = getenv("GA3C_RESPONDER_SPIN_US")) helper.spin_us = atoi(e);
+    helper.th = std::thread([&helper] { helper.run(); });
+  }
+  struct StopHelper {
+    Responder& r; ga3c_serve_stats* st; bool on;
+    ~StopHelper() { if (on) { r.stop(); st->ns_respond += r.ns; } }
+  } stop_helper{helper, st, use_helper};
+  int cur = 0;
   for (;;) {
     const int64_t t0 = now_ns();
     const int64_t left_ms = (t_end - t0 + 999999) / 1000000;
     if (left_ms <= 0) return GA3C_H_OK;
-    const int n = ga3c_pq_pop_batch(shm, ids.data(), max_batch, (int)left_ms);
+    if (use_helper && helper.rc.load(std::memory_order_relaxed) < 0) return helper.rc.load();
+    const int n = ga3c_pq_pop_batch(shm, ids[cur].data(), max_batch, (int)left_ms);
     const int64_t t1 = now_ns();
     st->ns_pop += t1 - t0;
     if (n < 0) return n;
     if (n == 0) continue;
     int predicted = 0;
     for (int i = 0; i < n; ++i) {
-      if (ids[i] >= (uint32_t)h->cfg.max_agents) return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[i]);
-      offs[i] = h->agents_off + (int64_t)ids[i] * h->agent_stride;
-      agents[i] = (int32_t)ids[i];
-      flags[i] = shm->meta((int)ids[i])->req_flags;
+      if (ids[cur][i] >= (uint32_t)h->cfg.max_agents) return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[cur][i]);
+      offs[i] = h->agents_off + (int64_t)ids[cur][i] * h->agent_stride;
+      agents[i] = (int32_t)ids[cur][i];
+      flags[i] = shm->meta((int)ids[cur][i])->req_flags;
       predicted += (flags[i] & GA3C_REQ_NO_PREDICT) ? 0 : 1;
     }
-    const int rc = serve(net, offs.data(), agents.data(), flags.data(), n, p.data(), v.data());
+    const int rc = serve(net, offs.data(), agents.data(), flags.data(), n, p[cur].data(), v[cur].data());
     if (rc < 0) return fail(GA3C_H_ECALLBACK, "serve callback failed with %d on a batch of %d", rc, n);
     const int64_t t2 = now_ns();
-    const int rr = ga3c_pq_respond(shm, ids.data(), n, p.data(), v.data());
-    if (rr < 0) return rr;
-    const int64_t t3 = now_ns();
     st->ns_predict += t2 - t1;
-    st->ns_respond += t3 - t2;
+    if (use_helper) {
+      helper.post(ids[cur].data(), n, p[cur].data(), v[cur].data());   // (waits for the answers of the batch before)
+      cur = 1 - cur;
+    } else {
+      const int rr = ga3c_pq_respond(shm, ids[cur].data(), n, p[cur].data(), v[cur].data());
+      if (rr < 0) return rr;
+      st->ns_respond += now_ns() - t2;
+    }
     st->batches += 1;
     st->served += predicted;
     if (n > st->largest_batch) st->largest_batch = n;

@@ -154,7 +154,8 @@ int ga3c_pq_serve_pipelined_cached(ga3c_shm* shm, ga3c_predict_begin_cached_fn b
 int ga3c_pq_request_seq(ga3c_shm* shm, int32_t agent, int64_t* seq);
 /* The same loop for raw-frame requests (ga3c_pq_submit_flags): `serve` has the signature of ga3c_net_serve_frames
  * (include/ga3c_abi.h) and gets the popped slots' offsets, agent ids and request flags; stats->served counts the
- * predictions made (requests without GA3C_REQ_NO_PREDICT). */
+ * predictions made (requests without GA3C_REQ_NO_PREDICT).  The answers are given by a helper thread of the call, as in
+ * ga3c_pq_serve_pipelined (GA3C_RESPONDER=0: by the loop itself). */
 typedef int (*ga3c_serve_frames_fn)(void* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags,
                                     int32_t n, float* p, float* v);
 int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, int32_t max_batch, int32_t slice_ms,
