@@ -152,6 +152,28 @@ inline int gather_blocks(int B, int chunks, int max_blocks) {
 // small arrays that ride along with a gather (a batch's returns and one-hot actions, out of the pinned staging array):
 // copied by the last workgroup, so that staging a batch is ONE launch instead of a gather and two copy kernels
 struct SmallCopy { const float* src0; float* dst0; int n0; const float* src1; float* dst1; int n1; };
+// by one workgroup of 256 threads; eight loads per thread are requested before the first is stored: the sources lie in
+// pinned host memory, and a loop of load -> store paid a PCIe round trip per trip (four for a batch's one-hot actions)
+__device__ __forceinline__ void small_copy(const SmallCopy& sc) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* __restrict__ src = pass ? sc.src1 : sc.src0;
+    float* __restrict__ dst = pass ? sc.dst1 : sc.dst0;
+    const int n = pass ? sc.n1 : sc.n0;
+    for (int i0 = 0; i0 < n; i0 += 2048) {
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + 256 * k + (int)threadIdx.x;
+        t[k] = i < n ? src[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = i0 + 256 * k + (int)threadIdx.x;
+        if (i < n) dst[i] = t[k];
+      }
+    }
+  }
+}
 
 // ... and the rows' offsets travelling with the launch (n > 0) instead of being read out of the pinned array: every work
 // item's data loads waited for a scalar load over PCIe in front of them -- a round trip per trip of the loop
@@ -164,10 +186,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restr
   constexpr int PIECES = (CHUNKS + 255) / 256;
   const int items = B * PIECES;
   const int tid = threadIdx.x;
-  if (blockIdx.x == gridDim.x - 1) {
-    for (int i = tid; i < sc.n0; i += 256) sc.dst0[i] = sc.src0[i];
-    for (int i = tid; i < sc.n1; i += 256) sc.dst1[i] = sc.src1[i];
-  }
+  if (blockIdx.x == gridDim.x - 1) small_copy(sc);
   for (int it0 = blockIdx.x * 4; it0 < items; it0 += gridDim.x * 4) {
     uint4 v[4];
     bool live[4];
@@ -193,10 +212,7 @@ template <int CHUNKS>
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ base, const int64_t* __restrict__ offsets,
                                                         uint4* __restrict__ dst, int B, SmallCopy sc, const RowOffsets ro) {
   const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == 0 && b == 0) {
-    for (int i = threadIdx.x; i < sc.n0; i += 256) sc.dst0[i] = sc.src0[i];
-    for (int i = threadIdx.x; i < sc.n1; i += 256) sc.dst1[i] = sc.src1[i];
-  }
+  if (blockIdx.x == 0 && b == 0) small_copy(sc);
   // (batches beyond the 192 offsets that fit the arguments read them out of the pinned array: ro.n == 0)
   if (b < B && c < CHUNKS) dst[(size_t)b * CHUNKS + c] = *reinterpret_cast<const uint4*>(base + (ro.n ? ro.off[b < 192 ? b : 0] : offsets[b]) + (size_t)c * 16);
 }
