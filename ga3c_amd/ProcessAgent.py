@@ -64,6 +64,10 @@ class ProcessAgent(MP.Process):
             for e, r in zip(experiences, out):
                 e.reward = float(r)
             return experiences[:-1]
+        if (not Config.REWARD_CLIPPING and Config.DISCOUNTING and Config.USE_INTERMEDIATE_REWARD
+                and len(experiences) > 1):
+            # the reference reads the clipped reward it never computed (ProcessAgent.py:73-80); SURVEY section 9, Q2
+            raise UnboundLocalError("local variable 'r' referenced before assignment")
         out = tp.accumulate_rewards_fork([e.reward for e in experiences], discount_factor, terminal_reward,
                                          Config.DISCOUNTING, Config.USE_INTERMEDIATE_REWARD)
         for e, r in zip(experiences, out):

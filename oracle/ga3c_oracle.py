@@ -6,10 +6,13 @@ __graft_entry__.smoke() and by bench.py's cpu_baseline leg, always as the
 checker.  The product (ga3c_amd/) never imports it and has no CPU fallback.
 
 PARITY PINNING
-  * Plumbing (returns, batching): pinned.  `accumulate_rewards_fork` is checked
-    against the vectors recorded from the reference itself in SURVEY.md §8-a3 and
-    Appendix C; the batchers against traces produced by importing the reference's
-    own ThreadPredictor / ThreadTrainer (tests/golden/make_golden.py).
+  * Plumbing (returns, rollout arrays, action draws, batching): pinned to the
+    reference RUN in the build container (tests/golden/make_golden.py imports the
+    reference's own ProcessAgent / ThreadPredictor / ThreadTrainer and records
+    what they return): `accumulate_rewards_fork` against 100 recorded cases
+    (25 reward vectors x 4 flag settings, SURVEY.md §8-a3's hex vector among
+    them), `convert_data` and `select_action_index` against recorded arrays and
+    draws, the batchers against recorded traces.
   * NN numerics (forward, loss, gradients, RMSProp): PARITY UNPINNED.  The
     reference computes them inside TensorFlow 1.x (un-vendored, unpinned:
     "TensorFlow 1.0", /root/reference/README.md:8), which is absent from this
@@ -26,6 +29,8 @@ Reference lines followed (paths relative to /root/reference/ga3c):
   loss              NetworkVP_discrate.py:61,64-85
   optimizer         NetworkVP_discrate.py:99-105,120-123,130 + Config.py:111-122
   returns           ProcessAgent.py:69-84 (call site :148-149)
+  rollout arrays    ProcessAgent.py:86-100
+  action draw       ProcessAgent.py:109-115
   batching          ThreadPredictor.py:45-66, ThreadTrainer.py:42-62
   lr/beta schedule  Server.py:168-175
 """
@@ -274,6 +279,28 @@ def returns_nstep(rewards, gamma, bootstrap_value, rmin=-1.0, rmax=1.0):
         reward_sum = float(gamma) * reward_sum + r
         out[t] = reward_sum
     return out[:-1]
+
+
+def convert_data(states, actions, rewards, next_states, dones, num_actions):
+    """ProcessAgent.py:86-100 (discrete branch :93-98): a rollout as the five arrays the trainer queue carries --
+    states stacked as they are (f32), one-hot actions in f32 made from a float64 identity, returns left in f64."""
+    x_ = np.array(list(states))
+    x2_ = np.array(list(next_states))
+    done_ = np.array(list(dones))
+    a_ = np.eye(num_actions)[np.array(list(actions))].astype(np.float32)
+    r_ = np.array([r for r in rewards])
+    return x_, r_, a_, x2_, done_
+
+
+def select_action_index(prediction, u, play_mode=False):
+    """ProcessAgent.py:109-115: argmax in PLAY_MODE, else np.random.choice(actions, p=prediction).  `u` is the one
+    uniform that call draws from the global RandomState (random_sample()); the rest is choice()'s own arithmetic:
+    float64 cumulative sum of p, divided by its last entry, searchsorted(side='right')."""
+    if play_mode:
+        return int(np.argmax(prediction))
+    cdf = np.cumsum(np.asarray(prediction, dtype=np.float64))
+    cdf /= cdf[-1]
+    return int(np.searchsorted(cdf, u, side='right'))
 
 
 def predictor_batches(n_queued, batch_max):

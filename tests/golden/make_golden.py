@@ -4,10 +4,12 @@
 What is produced, and from what:
   batcher_traces.json   by importing the REFERENCE's own ThreadPredictor / ThreadTrainer / Config
                         (they import unchanged with numpy) and driving them with a fake server;
-  returns_fork.json     the vectors the survey recorded from the reference's
-                        ProcessAgent._accumulate_rewards.  ProcessAgent
-                        itself needs gym/skimage, which are absent and stay absent, so it is not
-                        imported here;
+  returns_fork.json     ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84) RUN here on 25 reward vectors x the
+                        four flag settings of SURVEY.md Appendix C (the survey's own hex vector is case 0);
+  process_agent.json    ProcessAgent.convert_data (:86-100) and select_action (:109-115) RUN here: array dtypes /
+                        shapes / values, and the draws under fixed np.random.seed values for A = 4, 6, 18 and in
+                        PLAY_MODE.  ProcessAgent is imported as SURVEY.md Appendix C records (empty modules named
+                        skimage / gym so that its import statements pass: see _import_reference_process_agent);
   nn_small.npz          f64-oracle outputs on seeded inputs (the NN path has no reference fixture:
                         "parity unpinned", see oracle/ga3c_oracle.py);
   frontend.npz          RGB frames and the uint8 84x84 planes Environment._preprocess (Environment.py:52-60) makes
@@ -121,45 +123,144 @@ def batcher_traces():
         json.dump(out, f, indent=1)
 
 
+def _import_reference_process_agent():
+    """The reference's own ProcessAgent module (ProcessAgent.py:44-178), imported the way SURVEY.md Appendix C records:
+    its import chain (ProcessAgent.py:36-39 -> EnvironmentPend.py:35-40 -> PyperEnvironment.py:1 -> pyper_env.py:19-20)
+    names `skimage` and `gym`, which this image does not have.  EMPTY modules of those names are registered so that the
+    import statements pass; they hold nothing but the two names the chain imports `from` them (bound to None), nothing of
+    either library is restated, and none of the three functions recorded below touches them (they are numpy + Config
+    only).  The reference's files stay where they are; only the recorded inputs / outputs leave this container."""
+    import types
+    import warnings
+    for name, names in (("skimage", ()), ("skimage.morphology", ("disk",)), ("skimage.color", ("rgb2gray",)),
+                        ("gym", ()), ("gym.wrappers", ())):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            for n in names:
+                setattr(mod, n, None)
+            sys.modules[name] = mod
+    sys.modules["gym"].wrappers = sys.modules["gym.wrappers"]
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import ProcessAgent as ref_pa               # reference module
+    from Config import Config as RefConfig          # reference module
+    from Experience import Experience as RefExperience
+    return ref_pa.ProcessAgent, RefConfig, RefExperience
+
+
+SOURCE = "reference run by make_golden.py"
+
+
 def returns_fork():
-    # Recorded by the survey from the reference's ProcessAgent._accumulate_rewards
-    # (SURVEY.md §8-a3 golden vector, Appendix C flag table).  Data only.
-    data = dict(
-        source="SURVEY.md section 8-a3 + Appendix C (reference ProcessAgent.py:69-84 run at survey time)",
-        rewards=[0.0, 0.5, -3.0, 2.0, 1.0], gamma=0.99, terminal_reward=1.0,
-        cases=[
-            dict(reward_clipping=True, discounting=True, use_intermediate_reward=False,
-                 out_hex=["0x1.ebd33d7f3c762p-1", "0x1.f0cb07d0aed99p-1", "0x1.f5cfaacd9e83ep-1",
-                          "0x1.fae147ae147aep-1", "0x1.0p+0"],
-                 out_repr=[0.96059601, 0.9702989999999999, 0.9801, 0.99, 1.0]),
-            dict(reward_clipping=False, discounting=True, use_intermediate_reward=False,
-                 out_repr=[0.96059601, 0.9702989999999999, 0.9801, 0.99, 1.0]),
-            dict(reward_clipping=True, discounting=True, use_intermediate_reward=True,
-                 out_repr=[0.0, 0.5, -3.0, 2.0, 1.0]),
-            dict(reward_clipping=True, discounting=False, use_intermediate_reward=False,
-                 out_repr=[0.0, 0.5, -3.0, 2.0, 1.0]),
-        ],
-        convert_data_dtypes=dict(x_="float32", r_="float64", a_="float32", x2_="float32", done_="bool"))
-    # ORACLE-DERIVED cases (oracle/ga3c_oracle.py:accumulate_rewards_fork, NOT recorded from the reference): they pin the C
-    # ABI and the agents' rollout code to the restatement on the shapes the recorded vector does not cover -- T = 1, T = 2,
-    # zero / negative terminal rewards and a TIME_MAX + 1 = 6 row first rollout (ProcessAgent.py:157-162).  Kept under
-    # their own key so the reference-recorded vector above stays distinguishable.
-    import ga3c_oracle as o
+    """ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84) RUN on 25 reward vectors x the four flag settings of
+    SURVEY.md Appendix C; every number in the fixture is what the reference's function returned here."""
+    RefAgent, RefConfig, RefExperience = _import_reference_process_agent()
     rng = np.random.default_rng(606)
-    derived = []
+    inputs = [([0.0, 0.5, -3.0, 2.0, 1.0], 0.99, 1.0)]        # the survey's vector (terminal given separately there)
     for rewards, gamma in (([2.5], 0.99), ([7.0, -1.0], 0.5), ([0.0, 0.0, 0.0], 0.99), ([1.0, -1.0, 0.0, 0.0, 1.0, -1.0], 0.99),
                            ([0.25, 0.0, -0.75, 3.0, 0.0, 0.0], 0.99), (list(rng.normal(size=6)), 0.99),
                            (list(rng.normal(size=33)), 0.97), ([0.0] * 5 + [-1.0], 0.99)):
         rewards = [float(r) for r in rewards]
-        for disc, inter in ((True, False), (True, True), (False, False)):
-            out = o.accumulate_rewards_fork(rewards, gamma, rewards[-1], discounting=disc, use_intermediate_reward=inter)
-            derived.append(dict(rewards_hex=[r.hex() for r in rewards], gamma=gamma, terminal_reward_hex=rewards[-1].hex(),
-                                discounting=disc, use_intermediate_reward=inter, out_hex=[float(v).hex() for v in out]))
-    data["oracle_derived_note"] = ("computed by oracle/ga3c_oracle.py, not by the reference: regression vectors for the C ABI "
-                                   "and ProcessAgent (T=1, T=2, zero / negative terminal, TIME_MAX+1 rows)")
-    data["oracle_derived_cases"] = derived
+        inputs.append((rewards, gamma, rewards[-1]))          # call site :148-149: terminal = the last raw reward
+        inputs.append((rewards, gamma, 0.0))
+        inputs.append((rewards, 1.0, -rewards[-1]))
+    cases = []
+    keep = {k: getattr(RefConfig, k) for k in ("REWARD_CLIPPING", "DISCOUNTING", "USE_INTERMEDIATE_REWARD")}
+    try:
+        for rewards, gamma, terminal in inputs:
+            for clip, disc, inter in ((True, True, False), (False, True, False), (True, True, True), (True, False, False)):
+                RefConfig.REWARD_CLIPPING, RefConfig.DISCOUNTING, RefConfig.USE_INTERMEDIATE_REWARD = clip, disc, inter
+                exps = [RefExperience(None, 0, None, r, None, False) for r in rewards]
+                out = RefAgent._accumulate_rewards(exps, gamma, terminal)
+                assert out is exps
+                cases.append(dict(rewards_hex=[float(r).hex() for r in rewards], gamma=gamma,
+                                  terminal_reward_hex=float(terminal).hex(), reward_clipping=clip, discounting=disc,
+                                  use_intermediate_reward=inter, rows_out=len(out),
+                                  out_hex=[float(e.reward).hex() for e in out]))
+        # the one setting that does not return: clipping off + intermediate rewards on reads an unset name (:73-80)
+        RefConfig.REWARD_CLIPPING, RefConfig.DISCOUNTING, RefConfig.USE_INTERMEDIATE_REWARD = False, True, True
+        try:
+            RefAgent._accumulate_rewards([RefExperience(None, 0, None, r, None, False) for r in (1.0, 2.0)], 0.99, 2.0)
+            raised = None
+        except Exception as e:                      # noqa: BLE001 - the type is what is recorded
+            raised = type(e).__name__
+    finally:
+        for k, v in keep.items():
+            setattr(RefConfig, k, v)
+    data = dict(source=SOURCE, function="ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84)", cases=cases,
+                clip_off_intermediate_on_raises=raised)
     with open(os.path.join(HERE, "returns_fork.json"), "w") as f:
         json.dump(data, f, indent=1)
+
+
+def process_agent():
+    """ProcessAgent.convert_data (ProcessAgent.py:86-100) and ProcessAgent.select_action (:109-115) RUN here: dtypes,
+    shapes and values of the five arrays a rollout becomes, and the actions drawn under fixed np.random.seed values."""
+    RefAgent, RefConfig, RefExperience = _import_reference_process_agent()
+    rng = np.random.default_rng(707)
+    out = dict(source=SOURCE, convert_data=[], select_action=[])
+    keep = {k: getattr(RefConfig, k) for k in ("CONTINUOUS_INPUT", "PLAY_MODE")}
+    try:
+        RefConfig.CONTINUOUS_INPUT = False
+
+        class Self:                                 # convert_data reads self.num_actions only
+            pass
+
+        for num_actions, rows, state_shape in ((4, 1, (3, 3, 2)), (6, 6, (3, 3, 2)), (18, 5, (2, 2, 4)), (6, 2, (84, 84, 4))):
+            me = Self()
+            me.num_actions = num_actions
+            big = int(np.prod(state_shape)) > 64
+            states = [(rng.integers(0, 256, size=state_shape).astype(np.float32) / np.float32(128) - np.float32(1))
+                      for _ in range(rows + 1)]
+            actions = [int(a) for a in rng.integers(0, num_actions, size=rows)]
+            rewards = [float(r) for r in rng.normal(size=rows)]
+            dones = [False] * (rows - 1) + [True]
+            exps = [RefExperience(states[t], actions[t], None, rewards[t], states[t + 1], dones[t]) for t in range(rows)]
+            x_, r_, a_, x2_, done_ = RefAgent.convert_data(me, exps)
+            rec = dict(num_actions=num_actions, state_shape=list(state_shape), actions=actions,
+                       rewards_hex=[r.hex() for r in rewards], dones=dones,
+                       dtypes=dict(x_=str(x_.dtype), r_=str(r_.dtype), a_=str(a_.dtype), x2_=str(x2_.dtype),
+                                   done_=str(done_.dtype)),
+                       shapes=dict(x_=list(x_.shape), r_=list(r_.shape), a_=list(a_.shape), x2_=list(x2_.shape),
+                                   done_=list(done_.shape)),
+                       a_=a_.tolist(), r_hex=[float(v).hex() for v in r_], done_=[bool(v) for v in done_],
+                       x_is_stack_of_states=bool(all(np.array_equal(x_[t], states[t]) for t in range(rows))),
+                       x2_is_stack_of_next_states=bool(all(np.array_equal(x2_[t], states[t + 1]) for t in range(rows))))
+            if not big:                             # small states travel whole (f32 values are k/128 - 1: exact in JSON)
+                rec["states"] = [s.tolist() for s in states]
+                rec["x_"] = x_.tolist()
+                rec["x2_"] = x2_.tolist()
+            out["convert_data"].append(rec)
+
+        for num_actions in (4, 6, 18):
+            actions = np.arange(num_actions)
+            for kind in ("softmax", "peaked", "zeros", "onehot", "uniform"):
+                z = rng.normal(size=num_actions) * (8.0 if kind == "peaked" else 1.5)
+                if kind == "uniform":
+                    z[:] = 0.0
+                p = np.exp(z - z.max())
+                if kind == "zeros":
+                    p[rng.permutation(num_actions)[:num_actions // 2]] = 0.0
+                if kind == "onehot":
+                    p[:] = 0.0
+                    p[int(rng.integers(0, num_actions))] = 1.0
+                p = (p / p.sum()).astype(np.float32)        # a prediction is a float32 row of the policy head
+                for seed in (0, 1, 12345):
+                    RefConfig.PLAY_MODE = False
+                    np.random.seed(seed)
+                    draws = [int(RefAgent.select_action(actions, p)) for _ in range(24)]
+                    RefConfig.PLAY_MODE = True
+                    play = int(RefAgent.select_action(actions, p))
+                    out["select_action"].append(dict(num_actions=num_actions, kind=kind, seed=seed,
+                                                     prediction_f32_hex=[float(v).hex() for v in p],
+                                                     draws=draws, play_mode_action=play))
+    finally:
+        for k, v in keep.items():
+            setattr(RefConfig, k, v)
+    with open(os.path.join(HERE, "process_agent.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 def nn_small():
@@ -232,9 +333,10 @@ def frontend():
 
 
 if __name__ == "__main__":
-    frontend()
-    returns_fork()
-    nn_small()
-    batcher_traces()
+    # `python tests/golden/make_golden.py [name ...]`: all fixtures, or only the named ones
+    makers = dict(frontend=frontend, returns_fork=returns_fork, process_agent=process_agent, nn_small=nn_small,
+                  batcher_traces=batcher_traces)
+    for name in (sys.argv[1:] or list(makers)):
+        makers[name]()
     print("golden fixtures written to", HERE)
     os._exit(0)     # reference batcher threads are parked in blocking get()s

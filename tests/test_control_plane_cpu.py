@@ -94,17 +94,67 @@ def test_return_modes(cfg):
         assert out[t].reward == r
 
 
-def test_convert_data_dtypes_match_reference(cfg, golden_dir):
+def test_convert_data_matches_reference_recording(cfg, golden_dir):
+    """The product's ProcessAgent.convert_data against what the reference's convert_data (ProcessAgent.py:86-100)
+    returned in tests/golden/make_golden.py: dtypes, shapes, one-hot rows, returns, done flags, stacked states."""
     import json, os
+    from Experience import Experience
     from ProcessAgent import ProcessAgent
-    want = json.load(open(os.path.join(golden_dir, "returns_fork.json")))["convert_data_dtypes"]
+    g = json.load(open(os.path.join(golden_dir, "process_agent.json")))
+    assert g["source"] == "reference run by make_golden.py"
+    for rec in g["convert_data"]:
+        rows, shape = len(rec["actions"]), tuple(rec["state_shape"])
+        agent = ProcessAgent.__new__(ProcessAgent)
+        agent.num_actions = rec["num_actions"]
+        states = ([np.array(st, dtype=np.float32) for st in rec["states"]] if "states" in rec
+                  else [np.full(shape, t / 128.0 - 1.0, np.float32) for t in range(rows + 1)])
+        rewards = [float.fromhex(h) for h in rec["rewards_hex"]]
+        exps = [Experience(states[t], rec["actions"][t], None, rewards[t], states[t + 1], rec["dones"][t])
+                for t in range(rows)]
+        got = dict(zip(("x_", "r_", "a_", "x2_", "done_"), agent.convert_data(exps)))
+        assert {k: str(v.dtype) for k, v in got.items()} == rec["dtypes"]
+        assert {k: list(v.shape) for k, v in got.items()} == rec["shapes"]
+        assert got["a_"].tolist() == rec["a_"] and [float(v).hex() for v in got["r_"]] == rec["r_hex"]
+        assert [bool(v) for v in got["done_"]] == rec["done_"]
+        if "x_" in rec:
+            assert got["x_"].tolist() == rec["x_"] and got["x2_"].tolist() == rec["x2_"]
+    # uint8 states (STATE_TRANSPORT = 'u8') become the same float32 values k / 128 - 1 (Environment.py:59-60)
     agent = ProcessAgent.__new__(ProcessAgent)
     agent.num_actions = 3
     x_, r_, a_, x2_, done_ = agent.convert_data(_experiences([0.0, 1.0, -1.0]))
-    got = dict(x_=str(x_.dtype), r_=str(r_.dtype), a_=str(a_.dtype), x2_=str(x2_.dtype), done_=str(done_.dtype))
-    assert got == want
-    assert x_.shape == (3, 84, 84, 4) and a_.shape == (3, 3) and np.all(a_.sum(axis=1) == 1)
-    assert np.all(x_ == -1.0)                           # uint8 0 -> 0/128 - 1
+    assert x_.dtype == np.float32 and x_.shape == (3, 84, 84, 4) and np.all(x_ == -1.0)
+
+
+def test_accumulate_rewards_and_select_action_match_reference_recording(cfg, golden_dir):
+    """ProcessAgent._accumulate_rewards / select_action of the product, class-level, against the reference's recorded
+    outputs (same fixtures the C ABI and the oracle are held to)."""
+    import json, os
+    from ProcessAgent import ProcessAgent
+    g = json.load(open(os.path.join(golden_dir, "returns_fork.json")))
+    cfg.RETURN_MODE = 'fork'
+    for case in g["cases"]:
+        cfg.REWARD_CLIPPING, cfg.DISCOUNTING = case["reward_clipping"], case["discounting"]
+        cfg.USE_INTERMEDIATE_REWARD = case["use_intermediate_reward"]
+        rewards = [float.fromhex(h) for h in case["rewards_hex"]]
+        out = ProcessAgent._accumulate_rewards(_experiences(rewards), case["gamma"],
+                                               float.fromhex(case["terminal_reward_hex"]))
+        assert [float(e.reward).hex() for e in out] == case["out_hex"] and len(out) == case["rows_out"]
+    # the one flag setting under which the reference does not return (recorded exception type)
+    cfg.REWARD_CLIPPING, cfg.DISCOUNTING, cfg.USE_INTERMEDIATE_REWARD = False, True, True
+    assert g["clip_off_intermediate_on_raises"] == "UnboundLocalError"
+    with pytest.raises(UnboundLocalError):
+        ProcessAgent._accumulate_rewards(_experiences([1.0, 2.0]), 0.99, 2.0)
+    g = json.load(open(os.path.join(golden_dir, "process_agent.json")))
+    for case in g["select_action"]:
+        p = np.array([float.fromhex(h) for h in case["prediction_f32_hex"]], dtype=np.float32)
+        actions = np.arange(case["num_actions"])
+        cfg.PLAY_MODE = False
+        np.random.seed(case["seed"])
+        assert [ProcessAgent.select_action(actions, p) for _ in case["draws"]] == case["draws"]
+        np.random.seed(case["seed"])        # float64 copy of the row: the numpy path of select_action
+        assert [ProcessAgent.select_action(actions, p.astype(np.float64)) for _ in case["draws"]] == case["draws"]
+        cfg.PLAY_MODE = True
+        assert ProcessAgent.select_action(actions, p) == case["play_mode_action"]
 
 
 def test_select_action_draws_equal_numpy_choice(cfg):

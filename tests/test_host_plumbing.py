@@ -54,30 +54,31 @@ def test_hip_library_fails_loudly_without_a_gpu(mods):
 
 
 def test_returns_c_abi_bit_exact_vs_reference_vectors(mods, golden_dir):
+    """ga3c_returns_fork against what the reference's ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84) returned
+    when tests/golden/make_golden.py ran it: T = 1 ... 33, zero / negative terminal rewards, gamma = 1, all four flag
+    settings of SURVEY.md Appendix C -- bit for bit."""
     tp = mods[1]
     g = json.load(open(os.path.join(golden_dir, "returns_fork.json")))
+    assert g["source"] == "reference run by make_golden.py" and len(g["cases"]) == 100
     for case in g["cases"]:
-        got = tp.accumulate_rewards_fork(g["rewards"], g["gamma"], g["terminal_reward"], case["discounting"],
-                                         case["use_intermediate_reward"])
-        assert got.dtype == np.float64 and got.tolist() == case["out_repr"]
-        if "out_hex" in case:
-            assert [float(v).hex() for v in got] == [float.fromhex(h).hex() for h in case["out_hex"]]
-
-
-def test_returns_c_abi_bit_exact_vs_oracle_derived_vectors(mods, golden_dir):
-    """T = 1, T = 2, zero / negative terminal rewards, a TIME_MAX + 1 row rollout: vectors computed by the oracle (marked
-    as such in the fixture), compared bit for bit."""
-    tp = mods[1]
-    g = json.load(open(os.path.join(golden_dir, "returns_fork.json")))
-    assert len(g["oracle_derived_cases"]) >= 20
-    for case in g["oracle_derived_cases"]:
         rewards = [float.fromhex(h) for h in case["rewards_hex"]]
         got = tp.accumulate_rewards_fork(rewards, case["gamma"], float.fromhex(case["terminal_reward_hex"]),
                                          case["discounting"], case["use_intermediate_reward"])
-        assert [float(v).hex() for v in got] == case["out_hex"]
-        want = o.accumulate_rewards_fork(rewards, case["gamma"], float.fromhex(case["terminal_reward_hex"]),
-                                         discounting=case["discounting"], use_intermediate_reward=case["use_intermediate_reward"])
-        assert [float(v).hex() for v in want] == case["out_hex"]
+        assert got.dtype == np.float64 and len(got) == case["rows_out"]
+        assert [float(v).hex() for v in got] == case["out_hex"], case
+
+
+def test_select_action_c_abi_equals_reference_draws(mods, golden_dir):
+    """ga3c_select_action against the actions the reference's ProcessAgent.select_action (ProcessAgent.py:109-115)
+    drew under fixed np.random.seed values (A = 4, 6, 18; softmax rows, rows with exact zeros, one-hot rows)."""
+    tp = mods[1]
+    g = json.load(open(os.path.join(golden_dir, "process_agent.json")))
+    assert g["source"] == "reference run by make_golden.py"
+    for case in g["select_action"]:
+        p = np.array([float.fromhex(h) for h in case["prediction_f32_hex"]], dtype=np.float32)
+        np.random.seed(case["seed"])
+        got = [tp.select_action_index(p, np.random.random_sample()) for _ in case["draws"]]
+        assert got == case["draws"], case
 
 
 def test_returns_c_abi_equals_oracle_on_random_rollouts(mods):

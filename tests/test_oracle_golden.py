@@ -14,14 +14,52 @@ def _load(golden_dir, name):
 
 
 def test_returns_fork_bit_exact(golden_dir):
+    """Every case was RUN through the reference's ProcessAgent._accumulate_rewards (ProcessAgent.py:69-84) by
+    tests/golden/make_golden.py: 25 reward vectors x 4 flag settings, compared bit for bit."""
     g = _load(golden_dir, "returns_fork.json")
+    assert g["source"] == "reference run by make_golden.py" and "oracle_derived_cases" not in g
+    assert len(g["cases"]) == 100
     for case in g["cases"]:
-        got = o.accumulate_rewards_fork(g["rewards"], g["gamma"], g["terminal_reward"],
+        rewards = [float.fromhex(h) for h in case["rewards_hex"]]
+        got = o.accumulate_rewards_fork(rewards, case["gamma"], float.fromhex(case["terminal_reward_hex"]),
                                         discounting=case["discounting"],
                                         use_intermediate_reward=case["use_intermediate_reward"])
-        assert got == case["out_repr"]                       # exact f64 equality
-        if "out_hex" in case:
-            assert [float(v).hex() for v in got] == [float.fromhex(h).hex() for h in case["out_hex"]]
+        assert len(got) == case["rows_out"] == len(rewards)
+        assert [float(v).hex() for v in got] == case["out_hex"], case
+    # the survey's own vector (SURVEY.md section 8-a3) is case 0 of the recording
+    assert g["cases"][0]["out_hex"][:2] == ["0x1.ebd33d7f3c762p-1", "0x1.f0cb07d0aed99p-1"]
+
+
+def test_convert_data_equals_reference_recording(golden_dir):
+    g = _load(golden_dir, "process_agent.json")
+    assert g["source"] == "reference run by make_golden.py"
+    for rec in g["convert_data"]:
+        rows, shape = len(rec["actions"]), tuple(rec["state_shape"])
+        if "states" in rec:
+            states = [np.array(s, dtype=np.float32) for s in rec["states"]]
+        else:
+            states = [np.zeros(shape, np.float32) for _ in range(rows + 1)]
+        rewards = [float.fromhex(h) for h in rec["rewards_hex"]]
+        x_, r_, a_, x2_, done_ = o.convert_data(states[:-1], rec["actions"], rewards, states[1:], rec["dones"],
+                                                rec["num_actions"])
+        got = dict(x_=x_, r_=r_, a_=a_, x2_=x2_, done_=done_)
+        assert {k: str(v.dtype) for k, v in got.items()} == rec["dtypes"]
+        assert {k: list(v.shape) for k, v in got.items()} == rec["shapes"]
+        assert a_.tolist() == rec["a_"] and [float(v).hex() for v in r_] == rec["r_hex"]
+        assert [bool(v) for v in done_] == rec["done_"]
+        if "x_" in rec:
+            assert x_.tolist() == rec["x_"] and x2_.tolist() == rec["x2_"]
+
+
+def test_select_action_equals_reference_draws(golden_dir):
+    g = _load(golden_dir, "process_agent.json")
+    assert {c["num_actions"] for c in g["select_action"]} == {4, 6, 18}
+    for case in g["select_action"]:
+        p = np.array([float.fromhex(h) for h in case["prediction_f32_hex"]], dtype=np.float32)
+        np.random.seed(case["seed"])
+        us = [np.random.random_sample() for _ in case["draws"]]
+        assert [o.select_action_index(p, u) for u in us] == case["draws"], case
+        assert o.select_action_index(p, 0.5, play_mode=True) == case["play_mode_action"]
 
 
 def test_returns_is_sequential_product_not_pow():
