@@ -89,6 +89,10 @@ class Config:
                                         # pipelined predictor and trainer loops; Server falls back without them)
     STATE_CACHE_ACTIVE = False          # (set by Server for its agents: the cache is really in use)
     NATIVE_TRAINER = True               # ThreadTrainer's batch assembly in one native call (ga3c_tq_collect) when ZERO_COPY is on
+    CPU_AFFINITY = 'auto'               # where server threads and agents run (Placement.py): 'auto' = as many CPUs as the cgroup's
+                                        # quota allows, whole L3 domains next to the GPU; 'off'; or a list such as '0-15'
+    AGENT_CPUS = None                   # (set by Server when the placement keeps CPUs apart for the agents)
+    AGENT_SPIN_US = 0                   # > 0: an agent polls this long for its answer before it sleeps on the slot's futex
     PREDICTION_LINGER_US = 0            # > 0: a predictor holding fewer than PREDICTION_LINGER_BATCH requests after its
     PREDICTION_LINGER_BATCH = 0         # greedy drain keeps collecting this long (the reference never waits: 0)
     ROLLOUT_SLOTS = 0                   # rollout slots of the transport; 0 = MAX_QUEUE_SIZE (the reference's queue bound)

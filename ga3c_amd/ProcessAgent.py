@@ -17,6 +17,7 @@ The debug prints of :131,133,152 are not reproduced; x
 convert_data's signature but are not transported (Q10).
 """
 import multiprocessing as mp
+import os
 import time
 from datetime import datetime
 
@@ -215,6 +216,12 @@ class ProcessAgent(MP.Process):
     def run(self):
         for k, v in self.config.items():
             setattr(Config, k, v)
+        cpus = getattr(Config, "AGENT_CPUS", None)            # Placement.py: the server's batching threads keep CPUs of their own
+        if cpus:
+            try:
+                os.sched_setaffinity(0, cpus)
+            except OSError:
+                pass
         self.transport = tp.Transport.attach(self.transport_name)
         self.names_states = bool(getattr(Config, "STATE_CACHE_ACTIVE", False))
         self.requests = self.transport.request_seq(self.id)   # (not 0 when the id was another agent's before)

@@ -15,7 +15,8 @@ import time
 from Config import Config
 import DataParallel
 from Environment import Environment
-from NetworkVP import Network
+from NetworkVP import Network, _device_ordinal
+import Placement
 from ProcessAgent import ProcessAgent, config_snapshot
 from ProcessStats import ProcessStats
 from ThreadDynamicAdjustment import ThreadDynamicAdjustment
@@ -31,6 +32,10 @@ class Server:
         self.dp_lock = threading.Lock()
         self.batch_lock = threading.Lock()      # one trainer at a time fills a batch (ThreadTrainer.py)
         self.closing = False
+        # before anything is started: every thread and process created from here on inherits the placement (Placement.py)
+        self.placement = Placement.place(os.environ.get("GA3C_CPU_AFFINITY") or getattr(Config, "CPU_AFFINITY", "auto"),
+                                         _device_ordinal(Config.DEVICE))
+        Config.AGENT_CPUS = (self.placement or {}).get("agent_cpus")
         self.stats = ProcessStats()
         self.state_dim = self.get_state_dim()
         self.num_actions = self.get_num_action()
@@ -66,6 +71,8 @@ class Server:
             slots = Config.MAX_QUEUE_SIZE + (0 if (self.device_frontend or self.state_cache) else 2 * max(Config.TRAINERS, 2) * per_batch)
         self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
                                              slots, Config.TIME_MAX + 1, row_bytes)
+        if getattr(Config, "AGENT_SPIN_US", 0) > 0:
+            self.transport.set_spin(Config.AGENT_SPIN_US)
         if Config.PREDICTION_LINGER_US > 0:
             self.transport.set_linger(Config.PREDICTION_LINGER_US, Config.PREDICTION_LINGER_BATCH)
         self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,

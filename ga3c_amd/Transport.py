@@ -138,6 +138,9 @@ class Transport:
         nat.check_host(self._lib.ga3c_pq_request_seq(self._h, int(agent), C.byref(n)), "ga3c_pq_request_seq")
         return n.value
 
+    def set_spin(self, spin_us):
+        nat.check_host(self._lib.ga3c_pq_set_spin(self._h, int(spin_us)), "ga3c_pq_set_spin")
+
     def set_linger(self, linger_us, min_batch):
         nat.check_host(self._lib.ga3c_pq_set_linger(self._h, int(linger_us), int(min_batch)), "ga3c_pq_set_linger")
 

@@ -45,6 +45,7 @@ class ServeStats(C.Structure):     # include/ga3c_host.h: ga3c_serve_stats
 HIP_SIGNATURES = {
     "ga3c_last_error": (C.c_char_p, []),
     "ga3c_device_count": (C.c_int, [i32p]),
+    "ga3c_device_pci_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "ga3c_net_create": (C.c_int, [C.POINTER(NetConfig), C.POINTER(C.c_void_p)]),
     "ga3c_net_destroy": (C.c_int, [C.c_void_p]),
     "ga3c_net_param_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -134,6 +135,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_respond": (C.c_int, [C.c_void_p, u32p, C.c_int32, f32p, f32p]),
     "ga3c_frame_preprocess": (C.c_int, [u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, u8p]),
     "ga3c_pq_set_linger": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ga3c_pq_set_spin": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_pq_serve_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_pq_serve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_tq_acquire": (C.c_int, [C.c_void_p, C.c_int32]),

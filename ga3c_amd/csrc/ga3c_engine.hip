@@ -1375,6 +1375,15 @@ int ga3c_device_count(int32_t* count) {
   return GA3C_OK;
 }
 
+int ga3c_device_pci_bus_id(int32_t device, char* out, int32_t len) {
+  if (!out || len < 16) return fail(GA3C_EINVAL, "bad argument");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(GA3C_EINVAL, "device %d not in [0,%d)", device, n);
+  HIPCHK(hipDeviceGetPCIBusId(out, len, device));
+  return GA3C_OK;
+}
+
 int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (!cfg || !out) return fail(GA3C_EINVAL, "null argument");
   if (cfg->num_actions < 1 || cfg->num_actions > GA3C_MAX_ACTIONS)

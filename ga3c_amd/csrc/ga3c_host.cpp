@@ -10,6 +10,7 @@
 #include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
@@ -60,6 +61,13 @@ int64_t now_ns() {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec;
+}
+// the batching threads carry names (`top -H`, /proc/<pid>/task/*/comm): where the server's CPU time goes is read per name
+void name_this_thread(const char* name) {
+  thread_local const char* current = nullptr;
+  if (current == name) return;
+  current = name;
+  prctl(PR_SET_NAME, (unsigned long)name, 0, 0, 0);
 }
 int64_t now_ms() {
   struct timespec ts;
@@ -183,7 +191,8 @@ struct AgentMeta {   // lives right behind each agent's state bytes
   std::atomic<uint32_t> resp_seq;    // futex word: predictor -> agent
   uint32_t req_flags;                // written by the agent before it submits (GA3C_REQ_*), read by the predictor
   uint32_t req_epoch;                // times req_seq has wrapped (written by the agent only): request number = epoch << 32 | seq
-  uint32_t pad[59];
+  std::atomic<uint32_t> waiting;     // 1 while the agent is (about to be) asleep on resp_seq: only then does an answer cost a syscall
+  uint32_t pad[58];
 };
 static_assert(sizeof(AgentMeta) == 512, "AgentMeta must stay 512 bytes");
 
@@ -197,6 +206,8 @@ struct Header {
   uint32_t pad;
   std::atomic<int32_t> linger_us;      // ga3c_pq_set_linger: how long a predictor keeps collecting after the first request
   std::atomic<int32_t> linger_batch;   // ... unless it already holds this many
+  std::atomic<int32_t> spin_us;        // ga3c_pq_set_spin: how long an agent polls for its answer before it sleeps
+  int32_t pad2;
   Ring req, freeq, readyq;
 };
 
@@ -729,8 +740,16 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
   AgentMeta* m = shm->meta(agent);
   const uint32_t want = m->req_seq;
   const int64_t deadline = timeout_ms >= 0 ? now_ms() + timeout_ms : -1;
+  // An answer that is already there, or arrives within spin_us, costs neither side a system call: the agent announces its
+  // sleep in `waiting` (then looks once more), ga3c_pq_respond publishes the answer and wakes only an agent that has announced
+  // it.  Both sides use sequentially consistent accesses, so one of them always sees the other's store.
+  const int32_t spin_us = h->spin_us.load(std::memory_order_relaxed);
+  if (spin_us > 0 && m->resp_seq.load(std::memory_order_acquire) != want) {
+    const int64_t until = now_ns() + (int64_t)spin_us * 1000;
+    while (m->resp_seq.load(std::memory_order_acquire) != want && now_ns() < until) __builtin_ia32_pause();
+  }
   for (;;) {
-    const uint32_t got = m->resp_seq.load(std::memory_order_acquire);
+    uint32_t got = m->resp_seq.load(std::memory_order_acquire);
     if (got == want) break;
     if (h->closed.load(std::memory_order_acquire)) return GA3C_H_ECLOSED;
     int wait_ms = -1;
@@ -739,10 +758,19 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
       if (left <= 0) return GA3C_H_ETIMEOUT;
       wait_ms = (int)left;
     }
-    futex_wait(&m->resp_seq, got, wait_ms);
+    m->waiting.store(1, std::memory_order_seq_cst);
+    got = m->resp_seq.load(std::memory_order_seq_cst);
+    if (got != want) futex_wait(&m->resp_seq, got, wait_ms);
+    m->waiting.store(0, std::memory_order_relaxed);
   }
   memcpy(p, m->p, (size_t)h->cfg.num_actions * sizeof(float));
   *v = m->v;
+  return GA3C_H_OK;
+}
+
+int ga3c_pq_set_spin(ga3c_shm* shm, int32_t spin_us) {
+  if (!shm || spin_us < 0) return fail(GA3C_H_EINVAL, "bad argument");
+  shm->hdr()->spin_us.store(spin_us, std::memory_order_relaxed);
   return GA3C_H_OK;
 }
 
@@ -814,8 +842,8 @@ int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* 
     AgentMeta* m = shm->meta((int)ids[i]);
     memcpy(m->p, p + (size_t)i * A, (size_t)A * sizeof(float));
     m->v = v[i];
-    m->resp_seq.store(m->req_seq, std::memory_order_release);
-    futex_wake(&m->resp_seq, 1);
+    m->resp_seq.store(m->req_seq, std::memory_order_seq_cst);
+    if (m->waiting.load(std::memory_order_seq_cst) != 0) futex_wake(&m->resp_seq, 1);
   }
   return GA3C_H_OK;
 }
@@ -823,6 +851,7 @@ int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* 
 int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
                   int32_t slice_ms, ga3c_serve_stats* st) {
   if (!shm || !predict || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
+  name_this_thread("ga3c-predict");
   Header* h = shm->hdr();
   const int A = h->cfg.num_actions;
   std::vector<uint32_t> ids((size_t)max_batch);
@@ -862,6 +891,22 @@ int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_
 // long first -- no faster on a 16-core quota, and a core more); GA3C_RESPONDER=0 keeps the answers in the loop.  Measured
 // (profiles/README.md): +2 % predictions/s with 64 agents, +4 % with 32 -- the loop's cycle is the GPU's latency either way,
 // the agents' earlier requests wait in the queue instead.
+// GA3C_RESPONDER: who wakes the agents of a finished batch.
+//   0 (default)  the loop itself: in the pipelined loop after it has popped and begun the next batch (beside the GPU's work
+//                on it; at once when nothing is queued), in the frames loop right after the batch
+//   1            a helper thread of the call (round 3's default)
+//   2            loop and helper share a batch of 8 rows or more (rows [0, n/2) the loop, [n/2, n) the helper)
+//   3            the loop itself, always at once (before it pops the next batch)
+// Measured on the placed engine (ga3c_amd/Placement.py; profiles/README.md, round 4), predictions/s with modes 0 / 1 / 2 / 3:
+// 64 Python agents, states shipped 504 k / 368 k / 395 k / 421 k; frame queue on the device 510 k / - / 493 k; 32 Python
+// agents 329 k / - / 302 k / 301 k; 256 native agents, device queue 991 k / 949 k / 915 k; 64 native 629 k / - / 628 k.  The
+// helper only pays while wake calls are dear (~2 us each on a cold core: unplaced, round 3); on warm cores a wake is ~1 us,
+// the loop's own answers delay its next pop by less than a launch, and batches grow instead (92 rows against 54).
+int responder_mode() {
+  const char* he = getenv("GA3C_RESPONDER");
+  return he ? atoi(he) : 0;
+}
+
 struct Responder {
   ga3c_shm* shm = nullptr;
   std::thread th;
@@ -874,6 +919,7 @@ struct Responder {
   int64_t ns = 0;
   int spin_us = 0;
   void run() {
+    name_this_thread("ga3c-respond");
     uint32_t seen = 0;
     for (;;) {
       const int64_t t_idle = now_ns();
@@ -926,8 +972,9 @@ static int serve_pipelined_common(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga
   std::vector<int32_t> agents((size_t)max_batch);
   int cur = 0, n_prev = 0;
   const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
-  const char* he = getenv("GA3C_RESPONDER");
-  const bool use_helper = !he || atoi(he) != 0;
+  name_this_thread("ga3c-predict");
+  const int mode = responder_mode();
+  const bool use_helper = mode == 1 || mode == 2;
   Responder helper;
   if (use_helper) {
     helper.shm = shm;
@@ -990,8 +1037,20 @@ static int serve_pipelined_common(ga3c_shm* shm, ga3c_predict_begin_fn begin, ga
       st->batches += 1;
       st->served += n;
       if (n > st->largest_batch) st->largest_batch = n;
-      if (use_helper) {
-        helper.post(ids[cur].data(), n, p[cur].data(), v[cur].data());   // the buffers stay untouched until it has finished
+      if (mode == 3) {
+        const int64_t t4 = now_ns();
+        const int r3 = ga3c_pq_respond(shm, ids[cur].data(), n, p[cur].data(), v[cur].data());
+        st->ns_respond += now_ns() - t4;
+        if (r3 < 0) return r3;
+      } else if (use_helper) {
+        const int mine = (mode == 2 && n >= 8) ? n / 2 : 0;     // the buffers stay untouched until the helper has finished
+        helper.post(ids[cur].data() + mine, n - mine, p[cur].data() + (size_t)mine * A, v[cur].data() + mine);
+        if (mine) {
+          const int64_t t4 = now_ns();
+          const int r2 = ga3c_pq_respond(shm, ids[cur].data(), mine, p[cur].data(), v[cur].data());
+          st->ns_respond += now_ns() - t4;
+          if (r2 < 0) return r2;
+        }
       } else {
         n_prev = n;
       }
@@ -1029,8 +1088,9 @@ int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, i
   std::vector<int32_t> agents((size_t)max_batch);
   std::vector<int64_t> offs((size_t)max_batch);
   const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
-  const char* he = getenv("GA3C_RESPONDER");
-  const bool use_helper = !he || atoi(he) != 0;
+  name_this_thread("ga3c-predict");
+  const int mode = responder_mode();
+  const bool use_helper = mode == 1 || mode == 2;
   Responder helper;
   if (use_helper) {
     helper.shm = shm;
@@ -1065,7 +1125,13 @@ int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, i
     const int64_t t2 = now_ns();
     st->ns_predict += t2 - t1;
     if (use_helper) {
-      helper.post(ids[cur].data(), n, p[cur].data(), v[cur].data());   // (waits for the answers of the batch before)
+      const int mine = (mode == 2 && n >= 8) ? n / 2 : 0;
+      helper.post(ids[cur].data() + mine, n - mine, p[cur].data() + (size_t)mine * A, v[cur].data() + mine);   // (waits for the answers of the batch before)
+      if (mine) {
+        const int rr = ga3c_pq_respond(shm, ids[cur].data(), mine, p[cur].data(), v[cur].data());
+        if (rr < 0) return rr;
+        st->ns_respond += now_ns() - t2;
+      }
       cur = 1 - cur;
     } else {
       const int rr = ga3c_pq_respond(shm, ids[cur].data(), n, p[cur].data(), v[cur].data());
@@ -1119,6 +1185,7 @@ int ga3c_tq_collect(ga3c_shm* shm, int32_t min_rows, int32_t timeout_ms, int32_t
                     int32_t* n_slots, int32_t* slots, int64_t* row_offsets, float* returns, int32_t* actions,
                     int32_t cap_rows, int32_t cap_slots, int64_t* row_seq, int32_t* row_agent) {
   if (!shm || !rows || !n_slots || !slots || !row_offsets || !returns || !actions) return fail(GA3C_H_EINVAL, "null argument");
+  name_this_thread("ga3c-train");
   Header* h = shm->hdr();
   if (*rows < 0 || *n_slots < 0 || min_rows < 0) return fail(GA3C_H_EINVAL, "bad batch state");
   const int64_t row_bytes = h->cfg.rollout_row_bytes ? h->cfg.rollout_row_bytes : h->cfg.state_bytes;

@@ -57,6 +57,10 @@ typedef struct ga3c_net_config {
 
 const char* ga3c_last_error(void);
 int ga3c_device_count(int32_t* count);
+/* PCI address of a device ("0000:23:00.0", NUL-terminated into out[len]).  The host side places its threads and agent
+ * processes on the cores next to that device (ga3c_amd/Placement.py); the reference leaves placement to TensorFlow's
+ * `DEVICE` string alone (Config.py:62, NetworkVP.py:50). */
+int ga3c_device_pci_bus_id(int32_t device, char* out, int32_t len);
 
 /* Network.__init__ / session teardown.  Weights are zero until ga3c_net_set_arena(which = 0). */
 int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out);

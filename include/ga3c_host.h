@@ -95,6 +95,11 @@ int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
 int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags);
 int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags);   /* predictor side */
 int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
+/* How long ga3c_pq_wait polls for the answer before the agent announces its sleep and waits on the slot's futex (0 = not at
+ * all, the default: a GPU round trip is 60 us and more, and a polling agent holds a core).  An answer that arrives while the
+ * agent is still awake costs neither side a system call: ga3c_pq_respond wakes only agents that have announced their sleep.
+ * (wait_q.get() of ProcessAgent.py:105-106 blocks in a pipe read; this is the futex counterpart.) */
+int ga3c_pq_set_spin(ga3c_shm* shm, int32_t spin_us);
 /* Environment._update_frame_q + _get_current_state (Environment.py:62-74) for the 4-deep frame queue kept as one
  * little-endian uint32 per pixel (byte c = frame c, oldest first): out[i] = (in[i] >> 8) | (plane[i] << 24), i < n.  The
  * words of `out` are the [84,84,4] uint8 state with the new plane as its newest frame; `in` is left untouched (experiences
@@ -132,11 +137,12 @@ typedef struct ga3c_serve_stats {
 } ga3c_serve_stats;
 int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_t u8, int32_t max_batch,
                   int32_t slice_ms, ga3c_serve_stats* stats);
-/* The same loop with the answering off its critical path: the ~1.6 us per agent that waking it costs (a futex wake each)
- * are spent by a helper thread of the call, as soon as `end` has returned the batch's results, while the loop pops and
- * ENQUEUES (`begin`) the next batch.  With GA3C_RESPONDER=0 in the environment the loop answers batch k itself, after it has
- * begun batch k+1 (beside the GPU's work on it); with nothing queued batch k is answered at once either way.  Nothing is
- * held when the call returns.  `begin` / `end` have the signatures of ga3c_net_predict_gather_begin / _end
+/* The same loop with the answering off the GPU's critical path: the loop answers batch k (a futex wake per agent that is
+ * asleep, ~1 us each) after it has popped and ENQUEUED (`begin`) batch k+1, beside the GPU's work on it; with nothing
+ * queued batch k is answered at once.  GA3C_RESPONDER in the environment moves the answering: 1 = to a helper thread of the
+ * call, as soon as `end` has returned the results (round 3's default, worth it only while wakes land on cold cores);
+ * 2 = loop and helper share a batch; 3 = the loop, always before it pops the next batch; 0 = the default above.  Nothing
+ * is held when the call returns.  `begin` / `end` have the signatures of ga3c_net_predict_gather_begin / _end
  * (include/ga3c_abi.h).  Same return values. */
 typedef int (*ga3c_predict_begin_fn)(void* net, const int64_t* offsets, int32_t batch, int32_t u8, int32_t* ticket);
 typedef int (*ga3c_predict_end_fn)(void* net, int32_t ticket, int32_t batch, float* p, float* v);
@@ -154,8 +160,8 @@ int ga3c_pq_serve_pipelined_cached(ga3c_shm* shm, ga3c_predict_begin_cached_fn b
 int ga3c_pq_request_seq(ga3c_shm* shm, int32_t agent, int64_t* seq);
 /* The same loop for raw-frame requests (ga3c_pq_submit_flags): `serve` has the signature of ga3c_net_serve_frames
  * (include/ga3c_abi.h) and gets the popped slots' offsets, agent ids and request flags; stats->served counts the
- * predictions made (requests without GA3C_REQ_NO_PREDICT).  The answers are given by a helper thread of the call, as in
- * ga3c_pq_serve_pipelined (GA3C_RESPONDER=0: by the loop itself). */
+ * predictions made (requests without GA3C_REQ_NO_PREDICT).  The loop answers a batch before it pops the next one
+ * (GA3C_RESPONDER = 1 / 2: a helper thread of the call does, or shares it, as in ga3c_pq_serve_pipelined). */
 typedef int (*ga3c_serve_frames_fn)(void* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags,
                                     int32_t n, float* p, float* v);
 int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, int32_t max_batch, int32_t slice_ms,

@@ -413,6 +413,40 @@ def test_transport_rejects_double_submit_and_times_out(mods):
         t.close()
 
 
+def test_an_answer_that_is_already_there_costs_no_wake_and_a_spinning_agent_sees_it(mods):
+    """ga3c_pq_wait / ga3c_pq_respond with the waiter flag: an answer given before the agent waits, an answer that arrives
+    while it polls (ga3c_pq_set_spin) and an answer to an agent asleep on its futex all come back as they were sent."""
+    import threading
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_spin"), 4, 6, 32, 2, 3)
+    ids = np.zeros(8, np.uint32)
+    try:
+        for spin_us, delay in ((0, 0.0), (0, 0.05), (20000, 0.002), (50, 0.05)):
+            t.set_spin(spin_us)
+            t.submit(2)
+            assert t.pop_batch(ids, 100) == 1 and ids[0] == 2
+            got = {}
+
+            def agent():
+                got["r"] = t.wait(2, 2000)
+
+            if delay == 0.0:                                 # answered before anybody waits
+                t.respond(ids, 1, np.full(6, 0.5, np.float32), np.array([1.25], np.float32))
+            th = threading.Thread(target=agent)
+            th.start()
+            if delay:
+                time.sleep(delay)
+                t.respond(ids, 1, np.full(6, 0.5, np.float32), np.array([1.25], np.float32))
+            th.join(5)
+            assert not th.is_alive()
+            rc, p, v = got["r"]
+            assert rc == 0 and v == 1.25 and p.tolist() == [0.5] * 6
+            assert t.agent_idle(2)
+    finally:
+        t.shutdown()
+        t.close()
+
+
 def test_transport_many_threads_no_lost_or_duplicated_requests(mods):
     nat, tp, Config = mods
     n_agents, rounds = 24, 200
@@ -539,14 +573,19 @@ def test_native_serve_loop_batches_and_routes_like_the_reference_trace(mods, gol
         t.close()
 
 
-@pytest.mark.parametrize("helper", ["1", "0"])
+@pytest.mark.parametrize("helper", ["default", "0", "1", "2", "3"])
 @pytest.mark.parametrize("key", ["predictor_128", "predictor_32"])
 def test_pipelined_serve_loop_batches_routes_and_overlaps(mods, golden_dir, key, helper, monkeypatch):
-    """ga3c_pq_serve_pipelined: the same batching as the reference's trace and every agent its own answer.  The answers of
-    batch k are given by a helper thread as soon as the results are there (default), or -- GA3C_RESPONDER=0 -- by the loop
-    itself after it has BEGUN batch k+1 (the answering then runs beside the GPU's work, and while requests are queued batch
-    k is still unanswered when k+1 begins); the last batch, with nothing queued behind it, is answered at once either way."""
-    monkeypatch.setenv("GA3C_RESPONDER", helper)
+    """ga3c_pq_serve_pipelined: the same batching as the reference's trace and every agent its own answer, whoever gives the
+    answers (GA3C_RESPONDER, include/ga3c_host.h): 0 = the default = the loop itself after it has BEGUN batch k+1 (the answering
+    then runs beside the GPU's work, and while requests are queued batch k is still unanswered when k+1 begins); 1 = a helper
+    thread as soon as the results are there; 2 = loop and helper share the batch; 3 = the loop, before it pops batch k+1.
+    The last batch, with nothing queued behind it, is answered at once in every mode."""
+    if helper == "default":
+        monkeypatch.delenv("GA3C_RESPONDER", raising=False)
+        helper = "0"
+    else:
+        monkeypatch.setenv("GA3C_RESPONDER", helper)
     import ctypes as C
     nat, tp, Config = mods
     from ThreadPredictor import ThreadPredictor
@@ -612,6 +651,8 @@ def test_pipelined_serve_loop_batches_routes_and_overlaps(mods, golden_dir, key,
             before = done - begins[k - 1][1] if k else 0
             if helper == "0":
                 assert b[2] == before, (k, b, done)
+            elif helper == "3":
+                assert b[2] == done, (k, b, done)
             else:
                 assert before <= b[2] <= done, (k, b, done)
             done += b[1]

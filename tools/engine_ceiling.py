@@ -71,8 +71,28 @@ def main():
         except OSError:
             return 0, 0, 0
 
+    def thread_cpu(pid):
+        """CPU seconds (user + system) of every thread of `pid`, summed by thread name (/proc/<pid>/task/*/stat)."""
+        out = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        try:
+            for tid in os.listdir("/proc/%d/task" % pid):
+                try:
+                    raw = open("/proc/%d/task/%s/stat" % (pid, tid)).read()
+                except OSError:
+                    continue
+                name = raw[raw.index("(") + 1:raw.rindex(")")]
+                f = raw[raw.rindex(")") + 2:].split()
+                u, k = out.get(name, (0.0, 0.0))
+                out[name] = (u + int(f[11]) / tick, k + int(f[12]) / tick)
+        except OSError:
+            pass
+        return out
+
+    procs = {}
+
     def take():
-        return {"t": time.perf_counter(), "pred": srv.predictions_served, "steps": srv.training_step, "cg": cgroup(),
+        return {"t": time.perf_counter(), "cpu": {k: thread_cpu(v) for k, v in dict(procs, server=os.getpid()).items()}, "pred": srv.predictions_served, "steps": srv.training_step, "cg": cgroup(),
                 "eng": srv.model.stats() if hasattr(srv.model, "stats") else {},
                 "batches": sum(p.batches for p in srv.predictors),
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")},
@@ -80,11 +100,15 @@ def main():
 
     out = {}
 
+    agent_cpus = (getattr(srv, "placement", None) or {}).get("agent_cpus")
+
     def driver():
         time.sleep(1.0)                                   # predictors and trainers are up
         proc = subprocess.Popen([exe, srv.transport.name, str(args.agents), str(args.seconds - 2.0), "0" if args.no_train else "1"] +
                                 (["cache"] if getattr(srv, "state_cache", False) else []),
-                                stdout=subprocess.PIPE, text=True)
+                                stdout=subprocess.PIPE, text=True,
+                                preexec_fn=(lambda: os.sched_setaffinity(0, agent_cpus)) if agent_cpus else None)
+        procs["agents"] = proc.pid
         time.sleep(args.warm)
         snap["a"] = take()
         time.sleep(max(0.5, args.seconds - 2.0 - args.warm - 1.0))
@@ -107,8 +131,15 @@ def main():
     engine = {"predict_us_per_call": {k[8:-3]: round(eng[k] / pc / 1e3, 1) for k in eng if k.startswith("predict_") and k.endswith("_ns")},
               "train_us_per_call": {k[6:-3]: round(eng[k] / tc / 1e3, 1) for k in eng if k.startswith("train_") and k.endswith("_ns")},
               "train_reader_waits_per_call": round(eng.get("train_reader_waits", 0) / tc, 3)}
+    cpu = {}
+    for who in b["cpu"]:
+        for name, (u, k) in b["cpu"][who].items():
+            u0, k0 = a["cpu"].get(who, {}).get(name, (0.0, 0.0))
+            if (u - u0) + (k - k0) > 0.02 * dt:
+                cpu["%s:%s" % (who, name)] = [round((u - u0) / dt, 2), round((k - k0) / dt, 2)]
     print(json.dumps({
-        "engine": engine, "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / dt, 2), "throttled_periods": b["cg"][1] - a["cg"][1],
+        "cpu_cores_by_thread_name_user_sys": cpu, "us_cpu_per_prediction": round(sum(x + y for x, y in cpu.values()) * dt / max(pred, 1) * 1e6, 2),
+        "placement": getattr(srv, "placement", None), "engine": engine, "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / dt, 2), "throttled_periods": b["cg"][1] - a["cg"][1],
                                      "throttled_s": round((b["cg"][2] - a["cg"][2]) / 1e6, 2)},
         "agents": args.agents, "native_agents": True, "frame_queue_on_device": bool(args.frame_queue_on_device), "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
         "hogwild": bool(args.hogwild), "window_s": round(dt, 2), "host_cores": os.cpu_count(),
