@@ -897,11 +897,12 @@ int ga3c_pq_serve(ga3c_shm* shm, ga3c_predict_rows_fn predict, void* net, int32_
 //   1            a helper thread of the call (round 3's default)
 //   2            loop and helper share a batch of 8 rows or more (rows [0, n/2) the loop, [n/2, n) the helper)
 //   3            the loop itself, always at once (before it pops the next batch)
-// Measured on the placed engine (ga3c_amd/Placement.py; profiles/README.md, round 4), predictions/s with modes 0 / 1 / 2 / 3:
-// 64 Python agents, states shipped 504 k / 368 k / 395 k / 421 k; frame queue on the device 510 k / - / 493 k; 32 Python
-// agents 329 k / - / 302 k / 301 k; 256 native agents, device queue 991 k / 949 k / 915 k; 64 native 629 k / - / 628 k.  The
-// helper only pays while wake calls are dear (~2 us each on a cold core: unplaced, round 3); on warm cores a wake is ~1 us,
-// the loop's own answers delay its next pop by less than a launch, and batches grow instead (92 rows against 54).
+// Measured on the placed engine (ga3c_amd/Placement.py; profiles/r04_engine_matrix.md), predictions/s with modes 0 / 1 / 2,
+// same window within each group: 256 native agents, frame queue on the device 1,032 k / 949 k / 956 k (16 CPUs), 991 k / - /
+// 915 k (64); 64 native 604 k / - / 641 k (16), 629 k / - / 628 k (64); 64 Python agents, device queue 456 k / 434 k / 443 k
+// (16), 510 k / - / 493 k (64); 32 Python agents 290 k / 281 k / 284 k (16), states shipped 329 k / - / 302 k, mode 3 301 k
+// (64).  The helper only pays while wake calls are dear (~2 us each on a cold core: unplaced, round 3); on warm cores a wake
+// is ~1 us, the loop's own answers delay its next pop by less than a launch, and batches grow instead (92 rows against 54).
 int responder_mode() {
   const char* he = getenv("GA3C_RESPONDER");
   return he ? atoi(he) : 0;
