@@ -18,8 +18,11 @@ A step is one pass of the hot path over one batch that is already resident in HB
   train leg (reported under "train"): one ThreadTrainer batch (configs[2]: 128 rows) through forward,
       loss, backward, RCCL all-reduce of the gradient arena when N > 1, RMSProp.
 Per-GPU work is fixed as N grows (weak scaling); predictions need no collective.
-torch is used here only as plumbing (process group for the barrier / max-over-ranks and the device
-sync); the product path is libga3c_hip.so via ctypes.
+No torch in this process: the device sync is ga3c_net_sync (hipStreamSynchronize on every stream of the
+network), the barrier and the max over ranks travel over the package's own control plane (DataParallel.Rendezvous:
+TCP sockets found through MASTER_ADDR / MASTER_PORT); the product path is libga3c_hip.so via ctypes.
+`value` / `ms_per_step` are HOST WALL-CLOCK time of the bracketed K-step block (rounds 1 and 2's definition; round 3
+quoted the GPU event span, which is now the extra `gpu_span_ms_per_step` / `value_gpu_span`).
 """
 import argparse
 import json
@@ -158,21 +161,22 @@ def main():
                      % (args.gpus, args.gpus))
         world, rank, local_rank = 1, 0, 0
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    if args.device_override >= 0:
-        local_rank = args.device_override
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
     import ga3c_amd  # noqa: F401
     from Config import Config
     from NetworkVP import Network
     import _native as nat
+    import DataParallel
+    import Placement
+    ndev = nat.C.c_int32()
+    if nat.hip_lib().ga3c_device_count(nat.C.byref(ndev)) != 0 or ndev.value < 1:
+        sys.exit("bench.py needs an MI355X: no HIP device")
+    if args.device_override >= 0:
+        local_rank = args.device_override
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    rv = DataParallel.Rendezvous(rank, world, tag="bench")      # barrier + max over ranks (no-ops at N = 1)
+    # the product's CPU placement (Server.__init__ does the same): this process's threads next to its GPU
+    placement = Placement.place(os.environ.get("GA3C_CPU_AFFINITY") or Config.CPU_AFFINITY, local_rank)
 
     B, A, K, W = args.batch, args.actions, args.steps, args.warmup
     Config.PREDICTION_BATCH_SIZE = B
@@ -183,16 +187,13 @@ def main():
     net = Network("gpu:%d" % local_rank, "bench", A, (84, 84, 4), max_batch=TB, predict_lanes=max(NP, 4))
     lib, h = net._lib, net._h
 
-    import DataParallel
     dp_error = None
     if world > 1:
         try:
-            DataParallel.attach(net, rank, world)      # RCCL communicator; the 128-byte id travels over the gloo group
+            DataParallel.attach(net, rank, world)      # RCCL communicator; the 128-byte id travels over the control plane
         except RuntimeError as e:                       # predictions need no collective: keep the headline leg alive
             dp_error = str(e)
-        flag = torch.tensor([0 if dp_error is None else 1])
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag[0]) and dp_error is None:
+        if rv.reduce([0 if dp_error is None else 1])[0] and dp_error is None:
             dp_error = "RCCL communicator failed on another rank"
 
     # synthetic inputs of the reference's shape and value set
@@ -204,18 +205,21 @@ def main():
     nat.check(lib.ga3c_net_upload(h, nat.ptr(x_tb), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload")
     lr, beta = float(Config.LEARNING_RATE_START), float(Config.BETA_START)
 
+    def device_sync(handle=None):
+        nat.check(lib.ga3c_net_sync(handle or h), "sync")
+
     def barrier_sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        rv.barrier()
+        device_sync()
 
     def timed_block(mode, steps, lanes=0, rows=None):
         """EXACTLY `steps` steps between barrier + synchronize on both sides.  Returns (GPU span, host wall), both in
-        seconds and both the max over ranks.  GPU span = HIP events on the streams the steps run on: first start event to
-        last end event of the block (ga3c_net_last_lanes_gpu_ms; the train stream's own event pair for the train leg).
-        The host wall clock around the same block also contains the launch latency of the block's first kernel, the
-        wake-up of the synchronising host threads and the Python / ctypes / torch.cuda.synchronize() calls: ~50 us, a
-        seventh of a 20-step block of this path and nothing of a 300-step one."""
+        seconds and both the max over ranks.  Host wall = the clock around the block, from behind the first barrier + sync to
+        behind the closing sync: what `value` is computed from.  GPU span = HIP events on the streams the steps run on: first
+        start event to last end event of the block (ga3c_net_last_lanes_gpu_ms; the train stream's own event pair for the
+        train leg).  The wall clock also contains the launch latency of the block's first kernel, the wake-up of the
+        synchronising host threads and the Python / ctypes calls: tens of microseconds, a seventh of a 20-step block of this
+        path and nothing of a 300-step one."""
         ev_ms, gpu_ms = nat.C.c_float(), nat.C.c_float()
         rows = B if rows is None else rows
         barrier_sync()
@@ -225,14 +229,12 @@ def main():
             nat.check(lib.ga3c_net_last_lanes_gpu_ms(h, nat.C.byref(gpu_ms)), "last_lanes_gpu_ms")
         else:
             nat.check(lib.ga3c_net_time_resident(h, mode, rows, steps, lr, beta, nat.C.byref(gpu_ms)), "time_resident")
-        torch.cuda.synchronize()
+        device_sync()
         t1 = time.perf_counter()
         gpu_s, wall_s = gpu_ms.value * 1e-3, t1 - t0
         if world > 1:
-            dist.barrier()
-            tmax = torch.tensor([gpu_s, wall_s], dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            gpu_s, wall_s = float(tmax[0]), float(tmax[1])
+            rv.barrier()
+            gpu_s, wall_s = rv.reduce([gpu_s, wall_s])
         return gpu_s, wall_s
 
     MIN_TIMED_S, MAX_BLOCKS = 0.05, 400
@@ -249,10 +251,8 @@ def main():
             walls.append(w)
             total += w
             more = 1 if (total < MIN_TIMED_S and len(walls) < MAX_BLOCKS) else 0
-            if world > 1:
-                flag = torch.tensor([more if rank == 0 else 0])
-                dist.broadcast(flag, src=0)
-                more = int(flag[0])
+            if world > 1:                                  # the count is decided on rank 0's clock
+                more = int(rv.reduce([more if rank == 0 else 0])[0])
             if not more:
                 break
         if tag:
@@ -266,17 +266,17 @@ def main():
     if W > 0:
         nat.check(lib.ga3c_net_time_predict_lanes(h, B, W, NP, nat.C.byref(ev_ms)), "warmup")
     if args.lanes_only:      # child of the 8-hardware-queue extra (see below): the lane sweep and nothing else
-        res = {str(nl): K * B / timed(0, K, lanes=nl)[0] for nl in (1, 2, 3, 4)}
+        res = {str(nl): K * B / timed(0, K, lanes=nl)[1] for nl in (1, 2, 3, 4)}
         net.close()
         print(json.dumps(dict(res, hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES"))))
         return
-    pred_s, pred_wall_s = timed(0, K, lanes=NP, tag="predict")
-    one_s, _ = timed(0, K, lanes=1)
+    pred_gpu_s, pred_s = timed(0, K, lanes=NP, tag="predict")      # pred_s: host wall-clock of the median bracketed block
+    one_s = timed(0, K, lanes=1)[1]
     sweep = {}
     if not args.no_lane_sweep:
         for nl in (2, 3, 4):
             if nl != NP:
-                sweep[nl] = timed(0, K, lanes=nl)[0]
+                sweep[nl] = timed(0, K, lanes=nl)[1]
     dp_guard = None
     if world > 1:
         # the collective legs below have never run with N > 1 on hardware in this build's development (one-GPU box): if a
@@ -300,10 +300,10 @@ def main():
         dp_guard.daemon = True
         dp_guard.start()
     if dp_error is None:
-        train_s, train_wall_s = timed(1, K, tag="train")
-        train_tb_s, _ = timed(1, K, rows=TB)            # what the engine's trainers really assemble at MIN = B - 1
+        train_gpu_s, train_s = timed(1, K, tag="train")
+        train_tb_gpu_s, train_tb_s = timed(1, K, rows=TB)   # what the engine's trainers really assemble at MIN = B - 1
     else:                                               # no communicator: the data-parallel train leg is not measured
-        train_s, train_wall_s, train_tb_s = None, None, None
+        train_s, train_gpu_s, train_tb_s, train_tb_gpu_s = None, None, None, None
     allreduce_us = None
     if world > 1 and dp_error is None:      # the exchange step alone: 4.02 MB f32 sum all-reduce, events on the train stream
         barrier_sync()
@@ -313,9 +313,9 @@ def main():
     xk = np.ascontiguousarray(((x_tb + np.float32(1)) * np.float32(128)).astype(np.uint8))
     nat.check(lib.ga3c_net_upload_u8(h, nat.ptr(xk, nat.u8p), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload_u8")
     nat.check(lib.ga3c_net_time_predict_lanes(h, B, max(W, 1), NP, nat.C.byref(ev_ms)), "warmup")
-    u8_s, _ = timed(0, K, lanes=NP)
-    u8_train_s = timed(1, K)[0] if dp_error is None else None
-    u8_train_tb_s = timed(1, K, rows=TB)[0] if dp_error is None else None
+    u8_s = timed(0, K, lanes=NP)[1]
+    u8_train_s = timed(1, K)[1] if dp_error is None else None
+    u8_train_tb_s = timed(1, K, rows=TB)[1] if dp_error is None else None
     nat.check(lib.ga3c_net_upload(h, nat.ptr(x_tb), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload")
     comm_ranks, comm_rank, comm_dev = net.comm_info()
     if dp_guard is not None:
@@ -340,20 +340,24 @@ def main():
                                        "`value` is the NP = %d figure, the default of the reference and of this package; lanes "
                                        "beyond two share the two prediction streams (ga3c_net_create: the engine keeps to "
                                        "four busy streams)" % NP),
-            "ms_per_step_wall": pred_wall_s / K * 1e3,
-            "timing": "ms_per_step / value: GPU span of the median K-step block (HIP events on the lanes' streams, first start "
-                      "to last end, max over ranks); ms_per_step_wall: host clock around the same block between the two "
-                      "device synchronisations (adds ~50 us per block of launch latency, thread wake-up and Python calls)",
+            "gpu_span_ms_per_step": pred_gpu_s / K * 1e3, "value_gpu_span": world * K * B / pred_gpu_s,
+            "timing": "ms_per_step / value: HOST WALL-CLOCK of the median bracketed K-step block (barrier + device sync on "
+                      "both sides, max over ranks) -- the definition of rounds 1 and 2; round 3's headline was the GPU event "
+                      "span of the same block, kept here as gpu_span_ms_per_step / value_gpu_span (HIP events on the lanes' "
+                      "streams, first start to last end: without the launch latency of the block's first kernel and the "
+                      "wake-up of the synchronising host threads, which are a seventh of a 20-step block)",
+            "cpu_placement": placement, "torch_imported": "torch" in sys.modules,
             "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
                       "ms_per_step": train_s / K * 1e3 if train_s else None, "rows_per_step": world * B,
+                      "gpu_span_ms_per_step": train_gpu_s / K * 1e3 if train_gpu_s else None,
                       "trained_samples_per_sec": world * K * B / train_s if train_s else None,
                       "workload": "forward+loss+backward%s+RMSProp, %d rows per GPU (BASELINE configs[2])"
                                   % ("+RCCL all-reduce(sum) of 4.02 MB grads" if world > 1 else "", B),
                       "train_%d" % TB: {"rows_per_step": world * TB, "ms_per_step": train_tb_s / K * 1e3 if train_tb_s else None,
+                                         "gpu_span_ms_per_step": train_tb_gpu_s / K * 1e3 if train_tb_gpu_s else None,
                                          "steps_per_sec": K / train_tb_s if train_tb_s else None,
                                          "note": "the largest batch ThreadTrainer assembles at TRAINING_MIN_BATCH_SIZE = %d "
                                                  "(ThreadTrainer.py:49-59): MIN + TIME_MAX rows" % (B - 1)}},
-            "wall_ms_per_step": {"predict": pred_wall_s / K * 1e3, "train": train_wall_s / K * 1e3 if train_wall_s else None},
             "timed_blocks": dict(blocks_used, min_timed_ms=MIN_TIMED_S * 1e3,
                                  note="the bracketed K-step block is repeated until >= 50 ms are timed; ms_per_step and "
                                       "value are those of the MEDIAN block"),
@@ -478,12 +482,43 @@ def main():
         res = {}
         for nl in (1, 2, 4):
             nat.check(hog._lib.ga3c_net_time_train_lanes(hog._h, B, max(W, 1), nl, lr, beta, nat.C.byref(ms)), "warmup")
-            torch.cuda.synchronize()
+            device_sync(hog._h)
             nat.check(hog._lib.ga3c_net_time_train_lanes(hog._h, B, K, nl, lr, beta, nat.C.byref(ms)), "time_train_lanes")
             res[str(nl)] = K / (ms.value * 1e-3)
         out["train"]["hogwild_lanes"] = dict(res, unit="steps/s", note="Config.HOGWILD: NT train lanes update the weights "
                                              "concurrently and unlocked like the reference's trainer threads; the headline "
                                              "train figure above is the synchronous single-lane mode")
+        # ---- the data-parallel CODE PATH on one GPU: a one-rank RCCL communicator attached, so a step
+        # runs what every rank of an N-GPU job runs -- gradients to the arena, ncclAllReduce on the comm stream overlapped with
+        # the conv backward (two calls, events between the streams), the separate rmsprop kernel instead of the fused updates.
+        # The per-rank step cost an 8-GPU run starts from; the exchange itself (one rank: a copy) is not a scaling figure.
+        dpn = Network("gpu:%d" % local_rank, "bench_dp1", A, (84, 84, 4), max_batch=TB, predict_lanes=1)
+        nat.check(dpn._lib.ga3c_net_upload(dpn._h, nat.ptr(x_tb), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload")
+        dp1 = {}
+        try:
+            dpn.comm_init(Network.make_comm_id(), 0, 1)
+            for rows in (B, TB):
+                nat.check(dpn._lib.ga3c_net_time_resident(dpn._h, 1, rows, max(W, 5), lr, beta, nat.C.byref(ms)), "warmup")
+                walls, spans = [], []
+                while sum(walls) < MIN_TIMED_S and len(walls) < MAX_BLOCKS:
+                    device_sync(dpn._h)
+                    t0 = time.perf_counter()
+                    nat.check(dpn._lib.ga3c_net_time_resident(dpn._h, 1, rows, K, lr, beta, nat.C.byref(ms)), "time_resident")
+                    device_sync(dpn._h)
+                    walls.append(time.perf_counter() - t0)
+                    spans.append(ms.value * 1e-3)
+                dp1["rows_%d" % rows] = {"ms_per_step": float(np.median(walls)) / K * 1e3, "gpu_span_ms_per_step": float(np.median(spans)) / K * 1e3,
+                                         "steps_per_sec": K / float(np.median(walls))}
+            nat.check(dpn._lib.ga3c_net_time_allreduce(dpn._h, 50, nat.C.byref(ms)), "time_allreduce")
+            dp1["allreduce_us_one_rank"] = ms.value / 50 * 1e3
+            dp1["rccl_comm"] = dict(zip(("ranks", "rank", "device"), dpn.comm_info()))
+            dp1["note"] = ("one-rank RCCL communicator (ga3c_net_comm_init) on this GPU: the train step of the N-GPU code path -- "
+                           "non-fused rmsprop_kernel, slab_reduce without the update, dense1_bwd_tile without it, both "
+                           "ncclAllReduce calls and the comm-stream events -- beside the fused single-GPU step above")
+        except RuntimeError as e:
+            dp1["error"] = str(e)
+        out["train"]["train_dp_1rank"] = dp1
+        dpn.close()
         # ---- frame front-end: raw 210x160x3 frames -> uint8 planes -> device frame queues
         nf = 256                                            # one workgroup per frame, one frame per CU
         frng = np.random.Generator(np.random.PCG64(Config.RANDOM_SEED + 99))
@@ -594,18 +629,16 @@ def main():
         res = run_engine(None, args.e2e_seconds, args.e2e_agents, B, A, engine_group=group)
         group.close()
         guard.cancel()
-        tot = torch.tensor([res["predictions_per_sec"], res["training_steps_per_sec"], res["whole_run"]["training_steps_per_sec"]],
-                           dtype=torch.float64)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot = rv.reduce([res["predictions_per_sec"], res["training_steps_per_sec"], res["whole_run"]["training_steps_per_sec"]],
+                        op="sum")
         if rank == 0:
             out["e2e"] = {"predictions_per_sec": float(tot[0]), "training_steps_per_sec": float(tot[1]) / world,
                           "agents": world * args.e2e_agents, "ranks": world, "rank0": res,
                           "note": "one engine per GPU (%d agents, 2 predictors, 2 trainers each); predictions are summed over "
                                   "the ranks, a train step is a GLOBAL step (every rank's %d-row shard + RCCL all-reduce)"
                                   % (args.e2e_agents, B)}
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rv.barrier()
+    rv.close()
     if rank == 0:
         print(json.dumps(out))
 

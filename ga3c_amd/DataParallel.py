@@ -170,6 +170,22 @@ class Rendezvous:
             self.up.sendall(b"b")
             _recv_exact(self.up, 1)
 
+    def reduce(self, values, op="max"):
+        """Element-wise max / sum of a short list of floats over the ranks (everyone -> rank 0 -> everyone); the control
+        plane's own little all-reduce: bench.py's max-over-ranks timing and its error flags need nothing bigger."""
+        vals = [float(v) for v in values]
+        if self.world <= 1:
+            return vals
+        fmt = struct.Struct("<%dd" % len(vals))
+        if self.rank == 0:
+            rows = [vals] + [list(fmt.unpack(_recv_exact(s, fmt.size))) for s in self.peers]
+            out = [max(c) if op == "max" else sum(c) for c in zip(*rows)]
+            for s in self.peers:
+                s.sendall(fmt.pack(*out))
+            return out
+        self.up.sendall(fmt.pack(*vals))
+        return list(fmt.unpack(_recv_exact(self.up, fmt.size)))
+
     def close(self):
         for s in self.peers + ([self.up] if self.up else []):
             try:

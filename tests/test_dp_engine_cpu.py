@@ -223,3 +223,35 @@ def test_a_rank_that_never_joins_a_step_is_named_and_the_group_stops(tmp_path, m
     assert "rank 1 " in raised[0] and "train step 21" in raised[0]
     assert "rank 1 " in raised[1] and "rank 1 " in raised[2]          # every rank names the same late rank
     assert steps == [20, 20, 20] and took < 10
+
+
+def test_rendezvous_reduce_is_the_max_and_the_sum_over_the_ranks(tmp_path):
+    """bench.py's max-over-ranks timing and its summed engine rates travel over the control plane's own reduce (three
+    ranks over real sockets; one rank alone gets its values back)."""
+    import threading
+    import ga3c_amd  # noqa: F401
+    import DataParallel as dp
+    world, port = 3, 46000 + os.getpid() % 10000
+    got = {}
+
+    def run(rank):
+        rv = dp.Rendezvous(rank, world, tag="r", addr="127.0.0.1", port=port, directory=str(tmp_path))
+        try:
+            a = rv.reduce([1.5 * rank, -float(rank), 7.0])
+            rv.barrier()
+            b = rv.reduce([1.0 + rank, 0.25], op="sum")
+            got[rank] = (a, b)
+        finally:
+            rv.barrier()
+            rv.close()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30)
+    assert sorted(got) == [0, 1, 2]
+    for rank in range(world):
+        assert got[rank] == ([3.0, 0.0, 7.0], [6.0, 0.75])
+    solo = dp.Rendezvous(0, 1)
+    assert solo.reduce([2.0, 3.0]) == [2.0, 3.0]

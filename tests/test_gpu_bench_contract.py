@@ -31,6 +31,12 @@ def test_bench_line_contract(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "predictions/s" and c["sample"]
     assert d["train"]["value"] > 100 and d["e2e"]["predictions_per_sec"] > 100
+    # value is host wall-clock of the bracketed block; the GPU event span of the same block is an extra and can only be shorter
+    assert 0 < d["gpu_span_ms_per_step"] <= d["ms_per_step"] and d["value_gpu_span"] >= d["value"]
+    assert d["torch_imported"] is False                 # device sync and rank plumbing are the package's own
+    dp1 = d["train"]["train_dp_1rank"]                  # the N-GPU code path timed with a one-rank communicator
+    assert "error" not in dp1 and dp1["rccl_comm"]["ranks"] == 1
+    assert dp1["rows_128"]["steps_per_sec"] > 100 and dp1["rows_132"]["steps_per_sec"] > 100
 
 
 @pytest.mark.timeout(400)
