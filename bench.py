@@ -495,6 +495,9 @@ def main():
         dpn = Network("gpu:%d" % local_rank, "bench_dp1", A, (84, 84, 4), max_batch=TB, predict_lanes=1)
         nat.check(dpn._lib.ga3c_net_upload(dpn._h, nat.ptr(x_tb), nat.ptr(y_r_tb), nat.ptr(act_tb), TB), "upload")
         dp1 = {}
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)          # RCCL prints its version banner on stdout when a communicator is made: this
+        os.dup2(2, 1)                     # process's stdout carries the ONE JSON line and nothing else
         try:
             dpn.comm_init(Network.make_comm_id(), 0, 1)
             for rows in (B, TB):
@@ -517,6 +520,9 @@ def main():
                            "ncclAllReduce calls and the comm-stream events -- beside the fused single-GPU step above")
         except RuntimeError as e:
             dp1["error"] = str(e)
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         out["train"]["train_dp_1rank"] = dp1
         dpn.close()
         # ---- frame front-end: raw 210x160x3 frames -> uint8 planes -> device frame queues

@@ -170,19 +170,27 @@ class Network:
         return s.value
 
     def get_variables_names(self):
-        return [n + ":0" for n in PARAM_ORDER]
+        """NetworkVP.py:284-285; the names come out of the library's own table (ga3c_net_param_name)."""
+        n = self._lib.ga3c_net_num_params(self._h)
+        return [self._lib.ga3c_net_param_name(self._h, i).decode() + ":0" for i in range(n)]
 
-    def get_variable_value(self, name):
-        key = name[:-2] if name.endswith(":0") else name
-        off, size = self._offsets[key]
-        return self.get_arena(0)[off:off + size].reshape(param_shapes(self.num_actions)[key])
+    def _param_info(self, name):
+        off, count, ndim = C.c_int64(), C.c_int64(), C.c_int32()
+        shape = (C.c_int64 * 4)()
+        nat.check(self._lib.ga3c_net_param_info(self._h, name.encode(), C.byref(off), C.byref(count), C.byref(ndim), shape),
+                  "ga3c_net_param_info")
+        return off.value, count.value, tuple(shape[d] for d in range(ndim.value))
 
-    def set_variable_value(self, name, value):
-        key = name[:-2] if name.endswith(":0") else name
-        off, size = self._offsets[key]
-        arena = self.get_arena(0)
-        arena[off:off + size] = nat.as_f32(value).ravel()
-        self.set_arena(0, arena)
+    def get_variable_value(self, name, which=0):
+        """NetworkVP.py:287-288 (which = 1 / 2: the variable's RMSProp slots, 3: its last gradient)."""
+        _, count, shape = self._param_info(name)
+        out = np.empty(count, dtype=np.float32)
+        nat.check(self._lib.ga3c_net_get_param(self._h, name.encode(), which, nat.ptr(out), count), "ga3c_net_get_param")
+        return out.reshape(shape)
+
+    def set_variable_value(self, name, value, which=0):
+        flat = nat.as_f32(value).ravel()
+        nat.check(self._lib.ga3c_net_set_param(self._h, name.encode(), which, nat.ptr(flat), flat.size), "ga3c_net_set_param")
 
     # ---- inference ---------------------------------------------------------------------------
     def _predict(self, x, want_z=False):
@@ -503,17 +511,8 @@ class Network:
         """Own on-disk format (.npz keyed by the TF variable names + RMSProp slots + step):
         a TF checkpoint cannot be written without TF."""
         os.makedirs("checkpoints", exist_ok=True)
-        theta, ms, mom = self.get_arena(0), self.get_arena(1), self.get_arena(2)
-        out = {"step": np.int64(self.get_global_step())}
-        for name in PARAM_ORDER:
-            off, size = self._offsets[name]
-            shape = param_shapes(self.num_actions)[name]
-            out[name + ":0"] = theta[off:off + size].reshape(shape)
-            out[name + "/RMSProp:0"] = ms[off:off + size].reshape(shape)
-            out[name + "/RMSProp_1:0"] = mom[off:off + size].reshape(shape)
-        tmp = self._checkpoint_filename(episode) + ".tmp.npz"
-        np.savez(tmp, **out)
-        os.replace(tmp, self._checkpoint_filename(episode) + ".npz")
+        # written by the library itself (ga3c_net_save: an uncompressed .npz, written under a temporary name and renamed)
+        nat.check(self._lib.ga3c_net_save(self._h, (self._checkpoint_filename(episode) + ".npz").encode()), "ga3c_net_save")
 
     def load(self):
         if Config.LOAD_EPISODE > 0:
@@ -523,14 +522,5 @@ class Network:
             if not found:
                 raise FileNotFoundError("no checkpoint for %s" % self.model_name)
             filename = found[-1]
-        with np.load(filename, allow_pickle=False) as z:
-            arenas = [np.empty(self.param_count, np.float32) for _ in range(3)]
-            for name in PARAM_ORDER:
-                off, size = self._offsets[name]
-                for arena, suffix in zip(arenas, (":0", "/RMSProp:0", "/RMSProp_1:0")):
-                    arena[off:off + size] = z[name + suffix].ravel()
-            step = int(z["step"])
-        for which, arena in enumerate(arenas):
-            self.set_arena(which, arena)
-        nat.check(self._lib.ga3c_net_set_step(self._h, step))
+        nat.check(self._lib.ga3c_net_load(self._h, filename.encode()), "ga3c_net_load")
         return self._get_episode_from_filename(filename[:-4])

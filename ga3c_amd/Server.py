@@ -103,7 +103,7 @@ class Server:
         if Config.LOAD_CHECKPOINT:
             try:
                 self.stats.episode_count.value = self.model.load()
-            except (OSError, KeyError, ValueError) as e:
+            except (OSError, KeyError, ValueError, RuntimeError) as e:
                 print("checkpoint not loaded: %s" % e)
         self.training_step = 0
         self.frame_counter = 0

@@ -51,6 +51,13 @@ HIP_SIGNATURES = {
     "ga3c_net_param_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ga3c_net_get_arena": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
     "ga3c_net_set_arena": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_int64]),
+    "ga3c_net_num_params": (C.c_int32, [C.c_void_p]),
+    "ga3c_net_param_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
+    "ga3c_net_param_info": (C.c_int, [C.c_void_p, C.c_char_p, i64p, i64p, i32p, i64p]),
+    "ga3c_net_get_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, f32p, C.c_int64]),
+    "ga3c_net_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, f32p, C.c_int64]),
+    "ga3c_net_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ga3c_net_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ga3c_net_get_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ga3c_net_set_step": (C.c_int, [C.c_void_p, C.c_int64]),
     "ga3c_net_predict": (C.c_int, [C.c_void_p, f32p, C.c_int32, f32p, f32p, f32p]),

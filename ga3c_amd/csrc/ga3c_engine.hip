@@ -30,6 +30,7 @@
 
 #include "../../include/ga3c_abi.h"
 #include "ga3c_kernels.hpp"
+#include "ga3c_checkpoint.hpp"
 #include "ga3c_frontend.hpp"
 #include "ga3c_resample.hpp"
 
@@ -1639,6 +1640,152 @@ int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t co
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(net->tr.st));
   }
+  return GA3C_OK;
+}
+
+// ---- the variables by name (TensorFlow variable names, NetworkDNav.py:81-90, NetworkVP_discrate.py:60,63)
+namespace {
+constexpr int NPARAMS = 10;
+const char* const PARAM_NAMES[NPARAMS] = {"conv11/w", "conv11/b", "conv12/w", "conv12/b", "dense1/w", "dense1/b",
+                                          "logits_v/w", "logits_v/b", "logits_p/w", "logits_p/b"};
+struct ParamInfo { int64_t off, count; int ndim; int64_t shape[4]; };
+bool param_lookup(ga3c_net* net, const char* name, ParamInfo* pi) {
+  const int A = net->A;
+  const int64_t offs[NPARAMS + 1] = {OFF_W1, OFF_B1, OFF_W2, OFF_B2, OFF_WD, OFF_BD, OFF_WV, OFF_BV, OFF_WP, off_bp(A), net->n};
+  const int64_t shapes[NPARAMS][4] = {{8, 8, 4, 16}, {16, 0, 0, 0}, {4, 4, 16, 32}, {32, 0, 0, 0}, {FLAT, HID, 0, 0}, {HID, 0, 0, 0},
+                                      {HID, 1, 0, 0}, {1, 0, 0, 0}, {HID, A, 0, 0}, {A, 0, 0, 0}};
+  const int ndims[NPARAMS] = {4, 1, 4, 1, 2, 1, 2, 1, 2, 1};
+  std::string key(name ? name : "");
+  if (key.size() > 2 && key.compare(key.size() - 2, 2, ":0") == 0) key.resize(key.size() - 2);
+  for (int i = 0; i < NPARAMS; ++i)
+    if (key == PARAM_NAMES[i]) {
+      pi->off = offs[i]; pi->count = offs[i + 1] - offs[i]; pi->ndim = ndims[i];
+      for (int d = 0; d < 4; ++d) pi->shape[d] = shapes[i][d];
+      return true;
+    }
+  return false;
+}
+}  // namespace
+
+int32_t ga3c_net_num_params(ga3c_net* net) { return net ? NPARAMS : 0; }
+
+const char* ga3c_net_param_name(ga3c_net* net, int32_t index) {
+  return (net && index >= 0 && index < NPARAMS) ? PARAM_NAMES[index] : nullptr;
+}
+
+int ga3c_net_param_info(ga3c_net* net, const char* name, int64_t* offset, int64_t* count, int32_t* ndim, int64_t shape[4]) {
+  if (!net || !name) return fail(GA3C_EINVAL, "null argument");
+  ParamInfo pi;
+  if (!param_lookup(net, name, &pi)) return fail(GA3C_EINVAL, "no variable named %s", name);
+  if (offset) *offset = pi.off;
+  if (count) *count = pi.count;
+  if (ndim) *ndim = pi.ndim;
+  if (shape) for (int d = 0; d < 4; ++d) shape[d] = pi.shape[d];
+  return GA3C_OK;
+}
+
+// one variable's slice of an arena, under the locks ga3c_net_get_arena / set_arena take (nothing in flight meanwhile)
+static int param_copy(ga3c_net* net, const char* name, int which, float* out, const float* in, int64_t count) {
+  if (!net || !name || (!out && !in)) return fail(GA3C_EINVAL, "null argument");
+  ParamInfo pi;
+  if (!param_lookup(net, name, &pi)) return fail(GA3C_EINVAL, "no variable named %s", name);
+  if (count != pi.count) return fail(GA3C_EINVAL, "%s has %lld elements, not %lld", name, (long long)pi.count, (long long)count);
+  if (which < 0 || which > (in ? 2 : 3)) return fail(GA3C_EINVAL, "arena selector %d not in [0,%d]", which, in ? 2 : 3);
+  HIPCHK(hipSetDevice(net->cfg.device));
+  std::lock_guard<std::mutex> tl(net->tr.mu);
+  std::vector<std::unique_lock<std::mutex>> xl;
+  for (TrainLane* t : net->xtr) xl.emplace_back(t->mu);
+  std::unique_lock<std::shared_mutex> lk(net->wmu);
+  CHK(sync_all(net));
+  float* arena = arena_ptr(net, which);
+  if (out) {
+    HIPCHK(hipMemcpy(out, arena + pi.off, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return GA3C_OK;
+  }
+  HIPCHK(hipMemcpy(arena + pi.off, in, (size_t)count * sizeof(float), hipMemcpyHostToDevice));
+  if (which == 0) {                      // the packed copies of dense1/w and the conv filters follow the weights
+    hipLaunchKernelGGL(pack_wd_kernel, dim3(KSTEPS_DENSE), dim3(256), 0, net->tr.st, net->theta[net->latest] + OFF_WD,
+                       net->theta_pk[net->latest]);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(48), dim3(256), 0, net->tr.st, net->theta[net->latest], net->theta_pk[net->latest]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(net->tr.st));
+  }
+  return GA3C_OK;
+}
+
+int ga3c_net_get_param(ga3c_net* net, const char* name, int32_t which, float* out, int64_t count) {
+  if (!out) return fail(GA3C_EINVAL, "null argument");
+  return param_copy(net, name, which, out, nullptr, count);
+}
+
+int ga3c_net_set_param(ga3c_net* net, const char* name, int32_t which, const float* in, int64_t count) {
+  if (!in) return fail(GA3C_EINVAL, "null argument");
+  return param_copy(net, name, which, nullptr, in, count);
+}
+
+int ga3c_net_save(ga3c_net* net, const char* path) {
+  if (!net || !path) return fail(GA3C_EINVAL, "null argument");
+  std::vector<float> arena[3];
+  for (int w = 0; w < 3; ++w) {
+    arena[w].resize((size_t)net->n);
+    CHK(ga3c_net_get_arena(net, w, arena[w].data(), net->n));
+  }
+  const char* suffix[3] = {":0", "/RMSProp:0", "/RMSProp_1:0"};
+  std::vector<ga3c_ckpt::Member> members;
+  ga3c_ckpt::Member st;
+  st.name = "step"; st.descr = "<i8";
+  const int64_t step = net->step.load();
+  st.bytes.assign(reinterpret_cast<const uint8_t*>(&step), reinterpret_cast<const uint8_t*>(&step) + 8);
+  members.push_back(st);
+  for (int i = 0; i < NPARAMS; ++i) {
+    ParamInfo pi;
+    param_lookup(net, PARAM_NAMES[i], &pi);
+    for (int w = 0; w < 3; ++w) {
+      ga3c_ckpt::Member m;
+      m.name = std::string(PARAM_NAMES[i]) + suffix[w];
+      m.descr = "<f4";
+      m.shape.assign(pi.shape, pi.shape + pi.ndim);
+      const uint8_t* src = reinterpret_cast<const uint8_t*>(arena[w].data() + pi.off);
+      m.bytes.assign(src, src + (size_t)pi.count * sizeof(float));
+      members.push_back(std::move(m));
+    }
+  }
+  std::string err;
+  if (!ga3c_ckpt::write_npz(path, members, &err)) return fail(GA3C_ESTATE, "%s", err.c_str());
+  return GA3C_OK;
+}
+
+int ga3c_net_load(ga3c_net* net, const char* path) {
+  if (!net || !path) return fail(GA3C_EINVAL, "null argument");
+  std::map<std::string, ga3c_ckpt::Member> members;
+  std::string err;
+  if (!ga3c_ckpt::read_npz(path, &members, &err)) return fail(GA3C_ESTATE, "%s", err.c_str());
+  const char* suffix[3] = {":0", "/RMSProp:0", "/RMSProp_1:0"};
+  std::vector<float> arena[3];
+  for (int w = 0; w < 3; ++w) arena[w].resize((size_t)net->n);
+  for (int i = 0; i < NPARAMS; ++i) {
+    ParamInfo pi;
+    param_lookup(net, PARAM_NAMES[i], &pi);
+    for (int w = 0; w < 3; ++w) {
+      const std::string key = std::string(PARAM_NAMES[i]) + suffix[w];
+      auto it = members.find(key);
+      if (it == members.end()) return fail(GA3C_ESTATE, "%s holds no %s", path, key.c_str());
+      const ga3c_ckpt::Member& m = it->second;
+      int64_t elems = 1;
+      for (int64_t d : m.shape) elems *= d;
+      if (m.descr != "<f4" || elems != pi.count || m.bytes.size() != (size_t)pi.count * sizeof(float))
+        return fail(GA3C_ESTATE, "%s: %s is %s with %lld elements, this network wants <f4 with %lld", path, key.c_str(),
+                    m.descr.c_str(), (long long)elems, (long long)pi.count);
+      memcpy(arena[w].data() + pi.off, m.bytes.data(), m.bytes.size());
+    }
+  }
+  auto st = members.find("step");
+  if (st == members.end() || st->second.descr != "<i8" || st->second.bytes.size() != 8)
+    return fail(GA3C_ESTATE, "%s holds no int64 step", path);
+  int64_t step = 0;
+  memcpy(&step, st->second.bytes.data(), 8);
+  for (int w = 0; w < 3; ++w) CHK(ga3c_net_set_arena(net, w, arena[w].data(), net->n));
+  net->step.store(step);
   return GA3C_OK;
 }
 

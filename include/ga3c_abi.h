@@ -76,6 +76,26 @@ int ga3c_net_get_arena(ga3c_net* net, int32_t which, float* out, int64_t count);
 int ga3c_net_set_arena(ga3c_net* net, int32_t which, const float* in, int64_t count);
 int ga3c_net_get_step(ga3c_net* net, int64_t* step);        /* get_global_step, NetworkVP.py:233-235 */
 int ga3c_net_set_step(ga3c_net* net, int64_t step);
+/* The same variables BY NAME, for binders that do not want to re-derive the table above: get_variables_names /
+ * get_variable_value (NetworkVP.py:284-288) and the name-keyed tf.train.Saver (NetworkVP.py:62-64).
+ *   ga3c_net_num_params          10
+ *   ga3c_net_param_name(i)       "conv11/w", "conv11/b", "conv12/w", "conv12/b", "dense1/w", "dense1/b", "logits_v/w",
+ *                                "logits_v/b", "logits_p/w", "logits_p/b" (i in arena order; NULL outside [0, 10))
+ *   ga3c_net_param_info          offset and element count of the variable inside the arena, its rank and shape (<= 4 dims)
+ *   ga3c_net_get_param/set_param one variable of arena `which` (0 weights, 1 `ms`, 2 `mom`, 3 last gradient; set: 0..2);
+ *                                `count` must equal the variable's element count.  A name may carry TensorFlow's ":0". */
+int32_t ga3c_net_num_params(ga3c_net* net);
+const char* ga3c_net_param_name(ga3c_net* net, int32_t index);
+int ga3c_net_param_info(ga3c_net* net, const char* name, int64_t* offset, int64_t* count, int32_t* ndim, int64_t shape[4]);
+int ga3c_net_get_param(ga3c_net* net, const char* name, int32_t which, float* out, int64_t count);
+int ga3c_net_set_param(ga3c_net* net, const char* name, int32_t which, const float* in, int64_t count);
+/* save / load (NetworkVP.py:267-282): the whole training state -- every variable, its two RMSProp slots and `step` -- in ONE
+ * file.  The format is an uncompressed .npz (numpy.savez / numpy.load): members "<name>:0", "<name>/RMSProp:0",
+ * "<name>/RMSProp_1:0" with the variable's shape, and "step" (int64 scalar); a TensorFlow checkpoint cannot be written
+ * without TensorFlow.  The file name convention checkpoints/<model>_%08d (NetworkVP.py:267-272) is the caller's.  load refuses
+ * a file whose shapes do not match this network (another action count) and leaves the network untouched then. */
+int ga3c_net_save(ga3c_net* net, const char* path);
+int ga3c_net_load(ga3c_net* net, const char* path);
 
 /* predict_p_and_v (NetworkVP.py:248-252): x f32[B,84,84,4] NHWC host buffer ->
  * p f32[B,A] (softmax_p), v f32[B] (logits_v); z f32[B,A] (logits_p) if not NULL. */
