@@ -93,7 +93,9 @@ def run_engine(model, seconds, agents, B, A, frames="planes", predictors=2, trai
             steady = dict(whole, train_rows_per_step=srv.frame_counter / max(srv.training_step, 1), mean_predict_batch=None)
         res = dict(steady, agents=agents, predictors=predictors, trainers=trainers, whole_run=whole,
                    native_predictor_loop=bool(native and native[0]),
-                   rollouts_name_their_states=bool(getattr(srv, "state_cache", False) or getattr(srv, "device_frontend", False)))
+                   rollouts_name_their_states=bool(getattr(srv, "state_cache", False) or getattr(srv, "device_frontend", False)),
+                   lost_train_batches=getattr(srv, "lost_train_batches", 0),
+                   cpu_placement=(getattr(srv, "placement", None) or {}).get("why"))
         if model is None:
             srv.model.close()
         return res
@@ -338,8 +340,8 @@ def main():
                                   unit="predictions/s", hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                                   note="same K steps dealt to 1 .. 4 prediction lanes (one persistent host thread per lane); "
                                        "`value` is the NP = %d figure, the default of the reference and of this package; lanes "
-                                       "beyond two share the two prediction streams (ga3c_net_create: the engine keeps to "
-                                       "four busy streams)" % NP),
+                                       "beyond three share the three prediction streams (ga3c_net_create: the engine keeps to "
+                                       "four normal-priority streams)" % NP),
             "gpu_span_ms_per_step": pred_gpu_s / K * 1e3, "value_gpu_span": world * K * B / pred_gpu_s,
             "timing": "ms_per_step / value: HOST WALL-CLOCK of the median bracketed K-step block (barrier + device sync on "
                       "both sides, max over ranks) -- the definition of rounds 1 and 2; round 3's headline was the GPU event "

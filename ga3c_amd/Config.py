@@ -87,6 +87,8 @@ class Config:
                                         # rollouts NAME their states (agent, request number) instead of carrying them: no second
                                         # trip over PCIe for training (needs ZERO_COPY, STATE_TRANSPORT = 'u8', the native
                                         # pipelined predictor and trainer loops; Server falls back without them)
+    STATE_CACHE_DEPTH = 0               # states kept per agent (28,224 B each); 0 = four times an agent's fair share of the rows
+                                        # in flight plus four rollouts, at least 64 (2.3 MB per agent at the defaults)
     STATE_CACHE_ACTIVE = False          # (set by Server for its agents: the cache is really in use)
     NATIVE_TRAINER = True               # ThreadTrainer's batch assembly in one native call (ga3c_tq_collect) when ZERO_COPY is on
     CPU_AFFINITY = 'auto'               # where server threads and agents run (Placement.py): 'auto' = as many CPUs as the cgroup's

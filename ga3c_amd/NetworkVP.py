@@ -424,7 +424,8 @@ class Network:
 
     STAT_NAMES = ("predict_calls", "predict_rows", "predict_lane_wait_ns", "predict_launch_ns", "predict_sync_ns",
                   "predict_weight_waits", "train_calls", "train_rows", "train_stage_ns", "train_lane_wait_ns",
-                  "train_launch_ns", "train_sync_ns", "train_reader_waits", "predict_gpu_ns")
+                  "train_launch_ns", "train_sync_ns", "train_reader_waits", "predict_gpu_ns", "state_cache_bytes",
+                  "state_cache_lost_rows")
 
     def stats(self, reset=False):
         """Where the engine's calls spend their time (include/ga3c_abi.h: GA3C_STAT_*), as a dict of running totals."""

@@ -17,6 +17,7 @@ import DataParallel
 from Environment import Environment
 from NetworkVP import Network, _device_ordinal
 import Placement
+import _native as nat
 from ProcessAgent import ProcessAgent, config_snapshot
 from ProcessStats import ProcessStats
 from ThreadDynamicAdjustment import ThreadDynamicAdjustment
@@ -63,20 +64,44 @@ class Server:
         Config.STATE_CACHE_ACTIVE = self.state_cache         # (the agents read it from their configuration snapshot)
         if self.state_cache:
             row_bytes = 16
+        self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
+                                                             self.state_dim)
         # training_q.get() frees a queue entry at once (ThreadTrainer.py:49); zero-copy trainers keep a rollout's slot
         # until the GPU has read it, so the slots they hold come on top of the queue bound
         slots = int(Config.ROLLOUT_SLOTS)
-        if slots <= 0:
+
+        def slot_count():
             per_batch = -(-(Config.TRAINING_MIN_BATCH_SIZE + 1) // max(Config.TIME_MAX, 1))
-            slots = Config.MAX_QUEUE_SIZE + (0 if (self.device_frontend or self.state_cache) else 2 * max(Config.TRAINERS, 2) * per_batch)
+            return Config.MAX_QUEUE_SIZE + (0 if (self.device_frontend or self.state_cache) else 2 * max(Config.TRAINERS, 2) * per_batch)
+        if self.state_cache:
+            # What the ring of an agent must hold: the states it has stored and not yet seen trained.  Over ALL agents that is
+            # bounded by the rollouts in flight (every slot of the transport, two more being filled or handed over) plus the rows
+            # the trainers hold after they have given the slots back -- with the trainer count the dynamic adjustment may reach,
+            # not today's.  One agent owning all of it (886 states = 25 MB at the defaults, x max_agents) does not happen with
+            # agents that step at one rate: the ring gets four times the agent's fair share of that bound plus four rollouts,
+            # at least 64 states (Config.STATE_CACHE_DEPTH overrides); a row that does fall out is refused by the engine
+            # (GA3C_ELOST) and its batch dropped and counted, never trained on wrong bytes.
+            trainers = max(Config.TRAINERS, 2, 8 if Config.DYNAMIC_SETTINGS else 0)
+            total = ((slots if slots > 0 else slot_count()) + 2) * (Config.TIME_MAX + 1) + 8 + \
+                trainers * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1)
+            depth = int(getattr(Config, "STATE_CACHE_DEPTH", 0)) or \
+                min(total, max(64, 4 * -(-total // self.max_agents) + 4 * (Config.TIME_MAX + 1)))
+            try:
+                self.model.state_cache_config(self.max_agents, depth)
+                self.state_cache_depth = depth
+            except RuntimeError as e:            # no room in HBM: rollouts carry their states, as without the cache
+                print("[state cache] off: %s" % e, flush=True)
+                self.state_cache = False
+                Config.STATE_CACHE_ACTIVE = False
+                row_bytes = 16 if self.device_frontend else 0
+        if slots <= 0:
+            slots = slot_count()
         self.transport = tp.Transport.create(tp.unique_name(), self.max_agents, self.num_actions, state_bytes,
                                              slots, Config.TIME_MAX + 1, row_bytes)
         if getattr(Config, "AGENT_SPIN_US", 0) > 0:
             self.transport.set_spin(Config.AGENT_SPIN_US)
         if Config.PREDICTION_LINGER_US > 0:
             self.transport.set_linger(Config.PREDICTION_LINGER_US, Config.PREDICTION_LINGER_BATCH)
-        self.model = model if model is not None else Network(Config.DEVICE, Config.NETWORK_NAME, self.num_actions,
-                                                             self.state_dim)
         if self.dp is not None and hasattr(self.model, "comm_init"):
             DataParallel.attach(self.model, self.dp.rank, self.dp.world, rendezvous=self.dp.rv)
         # let the GPU read states straight out of the transport's slots (no host gather, no staging copy)
@@ -92,20 +117,15 @@ class Server:
             history = Config.FRAME_HISTORY or ((self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8 +
                                                max(Config.TRAINERS, 2) * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1))
             self.model.frames_config(self.max_agents, self.frame_shape[0], self.frame_shape[1], self.frame_shape[2], history)
-        if self.state_cache:
-            if not self.zero_copy:
-                raise RuntimeError("STATE_CACHE needs a model that reads the transport itself (register_transport)")
-            # how far an agent can be ahead of the trainers: every rollout in flight plus the one it is filling, plus the rows
-            # every trainer may hold after it has given their slots back (the bound of the plane history above)
-            depth = (self.transport.train_slots + 2) * (Config.TIME_MAX + 1) + 8 + \
-                max(Config.TRAINERS, 2) * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1)
-            self.model.state_cache_config(self.max_agents, depth)
+        if self.state_cache and not self.zero_copy:
+            raise RuntimeError("STATE_CACHE needs a model that reads the transport itself (register_transport)")
         if Config.LOAD_CHECKPOINT:
             try:
                 self.stats.episode_count.value = self.model.load()
             except (OSError, KeyError, ValueError, RuntimeError) as e:
                 print("checkpoint not loaded: %s" % e)
         self.training_step = 0
+        self.lost_train_batches = 0              # batches dropped because a named state had left the state cache
         self.frame_counter = 0
         self._served_by_retired = 0
         self.agents = []
@@ -207,7 +227,10 @@ class Server:
         self.stats.training_count.value += 1
         self.dynamic_adjustment.temporal_training_count += 1
         if Config.TENSORBOARD and self.stats.training_count.value % Config.TENSORBOARD_UPDATE_FREQUENCY == 0:
-            self.model.log(x_, r_, a_, self.training_step, **where)     # the batch just trained (Server.py:149-150)
+            try:
+                self.model.log(x_, r_, a_, self.training_step, **where)     # the batch just trained (Server.py:149-150)
+            except nat.StateLost:               # a named row left the state cache since the step: no summary this time
+                pass
 
     def worker_failed(self, worker, exc):
         """A predictor / trainer thread died (a HIP error, a row that left the plane history, ...).  The reference lets
@@ -230,7 +253,13 @@ class Server:
     def train_model_frames(self, agents, seqs, r_, a_, trainer_id):
         """train_model for rows whose states live in the device-side plane history (FRONTEND = 'device')."""
         if self.dp is None:
-            self.model.train_frames(agents, seqs, r_, a_)
+            try:
+                self.model.train_frames(agents, seqs, r_, a_)
+            except nat.StateLost as e:          # a row fell out of the state cache (GA3C_ELOST): nothing was trained, the batch
+                self.lost_train_batches += 1    # is dropped and counted; the first one says how to make room
+                if self.lost_train_batches == 1:
+                    print("[state cache] %s" % e, flush=True)
+                return
             self._count_train_step(agents.shape[0], None, r_, a_, frames=(agents, seqs))
             return
         with self.dp_lock:
@@ -301,6 +330,8 @@ class Server:
             self.zero_copy = False                  # unpin before the segment is unmapped
         if not stalled:
             self.transport.close()
+        else:
+            self.transport.unlink()                 # no unmap under a GPU that may still read it, but no /dev/shm leftover either
 
     @staticmethod
     def get_state_dim():

@@ -63,6 +63,11 @@ class Transport:
     def shutdown(self):
         self._lib.ga3c_shm_shutdown(self._h)
 
+    def unlink(self):
+        """Remove the segment's name and keep it mapped (ga3c_shm_unlink): a server that ends without close()."""
+        if self._h:
+            self._lib.ga3c_shm_unlink(self._h)
+
     def close(self):
         if self._h:
             self._raw = self.agent_states = None

@@ -119,6 +119,7 @@ HOST_SIGNATURES = {
     "ga3c_shm_create": (C.c_int, [C.c_char_p, C.POINTER(ShmConfig), C.POINTER(C.c_void_p)]),
     "ga3c_shm_attach": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ga3c_shm_close": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ga3c_shm_unlink": (C.c_int, [C.c_void_p]),
     "ga3c_shm_shutdown": (C.c_int, [C.c_void_p]),
     "ga3c_shm_base": (C.c_void_p, [C.c_void_p]),
     "ga3c_shm_bytes": (C.c_int64, [C.c_void_p]),
@@ -186,7 +187,16 @@ def host_lib():
     return _load(HOST_LIB, HOST_SIGNATURES)
 
 
+ELOST = -5         # GA3C_ELOST: a named row is no longer in the state cache
+
+
+class StateLost(RuntimeError):
+    """A train / evaluate batch named a state the engine no longer holds (GA3C_ELOST): nothing was trained."""
+
+
 def check(rc, what="ga3c call"):
+    if rc == ELOST:
+        raise StateLost("%s: %s" % (what, (hip_lib().ga3c_last_error() or b"").decode()))
     if rc < 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, (hip_lib().ga3c_last_error() or b"").decode()))
     return rc

@@ -279,6 +279,7 @@ struct ga3c_net {
   int cache_agents = 0, cache_depth = 0;
   std::mutex cache_mu;
   std::vector<int64_t> cache_newest;   // per agent: the newest request number stored (-1: none)
+  std::vector<int64_t> cache_tags;     // [agent][slot]: the request number the slot really holds (-1: nothing yet)
   bool frames_in_line = true;          // GA3C_FRAMES_IN_LINE=0: rows out of the plane history are staged on the staging stream, beside a step
   bool stop_events = true;             // GA3C_STOP_EVENTS=0: a prediction step's completion event is a hipEventRecord of its own
   bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
@@ -306,7 +307,7 @@ struct ga3c_net {
   LaneDrivers drv;
   float lanes_gpu_ms = 0.f;            // GPU-side span of the last ga3c_net_time_predict_lanes block (first start event .. last end event)
   int gather_max_blocks = 32;          // workgroups of the PCIe gather (GA3C_GATHER_BLOCKS; ga3c_kernels.hpp: gather_rows_kernel)
-  int lane_streams = 2;                // HIP streams the prediction lanes are spread over (GA3C_LANE_STREAMS)
+  int lane_streams = 3;                // HIP streams the prediction lanes are spread over (GA3C_LANE_STREAMS)
   std::atomic<int> stream_busy[16];    // lanes at work per prediction stream: take_lane prefers a lane whose stream is idle
   // where the engine's calls spend their time (ga3c_net_stats): nanoseconds / counts, relaxed atomics
   std::atomic<int64_t> stat[GA3C_STAT_COUNT];
@@ -1507,11 +1508,16 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   // time (tools/qmap.hip; profiles/README.md, "Hardware queues").  A prediction lane that lands on the train stream's
   // queue waits behind whole train steps, and a fifth busy queue makes all of them take turns -- either way the train step
   // is what slows down, and the engine's throughput is tied to it (every row served is trained once).  So the engine
-  // keeps to four streams that can be busy together: two for the prediction lanes, created first, then the train stream
-  // and its staging stream; lanes beyond two (Config.PREDICTORS > 2, the dynamic adjustment walking NP up) share those
-  // two streams in turn -- what the hardware queue would do to them anyway, without touching the train stream.
-  net->lane_streams = 2;
-  if (const char* e = getenv("GA3C_LANE_STREAMS")) net->lane_streams = atoi(e) > 0 ? atoi(e) : 2;
+  // keeps to FOUR normal-priority streams: three for the prediction lanes, created first, and the train lane's staging
+  // stream (the train stream itself is a high-priority stream with a queue of its own, alloc_train_lane; with the state cache
+  // or the frame queue on the device the staging is in line on it and the fourth stream stays idle).  Lanes beyond three
+  // (Config.PREDICTORS > 3, the dynamic adjustment walking NP up) share those three streams in turn -- what the hardware
+  // queue would do to them anyway.  Round 3 kept to two lane streams: NP = 3 then ran slower than NP = 2 (6.98 against 7.98 M
+  // resident predictions/s; 9.33 M with a stream each), and ThreadDynamicAdjustment's random walk passes through it; in the
+  // running engine three streams are worth +9-12 % with 3 or 4 predictor threads (64 Python agents: 460 -> 511 k and 428 ->
+  // 480 k predictions/s) and nothing with 2 (profiles/r04_engine_matrix.md, call h).
+  net->lane_streams = 3;
+  if (const char* e = getenv("GA3C_LANE_STREAMS")) net->lane_streams = atoi(e) > 0 ? atoi(e) : 3;
   if (net->graphs) net->lane_streams = 16;     // a stream under capture cannot be shared
   for (int i = 0; i < nl; ++i) {
     Lane* L = new (std::nothrow) Lane();
@@ -1902,25 +1908,40 @@ int ga3c_net_predict_gather(ga3c_net* net, const int64_t* offsets, int32_t batch
   return finish_predict(net, L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, p, v, z);
 }
 
-// rows' slots in the state cache, checked: row i = (agents[i], seqs[i]) -> byte offset; `advance`: they are being STORED
-// (the newest request number of an agent moves on), otherwise they are being READ and must still be there
-static int cache_offsets(ga3c_net* net, const int32_t* agents, const int64_t* seqs, int batch, bool advance, int64_t* out) {
+// rows' slots in the state cache: row i = (agents[i], seqs[i]) -> byte offset.  `store`: the rows are about to be STORED by a
+// step (nothing is recorded yet: cache_commit does that once the step is enqueued); otherwise they are being READ and every
+// slot must hold exactly the request it is named by, with room to spare before its agent's next predictions reach it
+constexpr int CACHE_SLACK = 4;
+static int cache_offsets(ga3c_net* net, const int32_t* agents, const int64_t* seqs, int batch, bool store, int64_t* out) {
   if (!net->cache_ring) return fail(GA3C_ESTATE, "no state cache configured (ga3c_net_state_cache_config)");
   std::lock_guard<std::mutex> g(net->cache_mu);
   for (int i = 0; i < batch; ++i) {
     const int ag = agents[i];
     if (ag < 0 || ag >= net->cache_agents) return fail(GA3C_EINVAL, "state cache: agent %d outside [0,%d)", ag, net->cache_agents);
     if (seqs[i] < 0) return fail(GA3C_EINVAL, "state cache: row %d has a negative request number", i);
-    int64_t& newest = net->cache_newest[(size_t)ag];
-    if (advance) {
-      if (seqs[i] > newest) newest = seqs[i];
-    } else if (seqs[i] > newest || newest - seqs[i] >= net->cache_depth) {
-      return fail(GA3C_ESTATE, "state cache: row %d, request %lld of agent %d, is not held (newest %lld, depth %d)", i,
-                  (long long)seqs[i], ag, (long long)newest, net->cache_depth);
+    const int64_t slot = seqs[i] % net->cache_depth;
+    if (!store) {
+      const int64_t newest = net->cache_newest[(size_t)ag], tag = net->cache_tags[(size_t)ag * net->cache_depth + slot];
+      if (tag != seqs[i] || newest - seqs[i] >= net->cache_depth - CACHE_SLACK) {
+        stat_add(net, GA3C_STAT_STATE_CACHE_LOST, batch);
+        return fail(GA3C_ELOST, "state cache: row %d, request %lld of agent %d, is not held (slot holds %lld, newest %lld, depth %d): "
+                    "raise Config.STATE_CACHE_DEPTH", i, (long long)seqs[i], ag, (long long)tag, (long long)newest, net->cache_depth);
+      }
     }
-    out[i] = ((int64_t)ag * net->cache_depth + seqs[i] % net->cache_depth) * (int64_t)XS;
+    out[i] = ((int64_t)ag * net->cache_depth + slot) * (int64_t)XS;
   }
   return GA3C_OK;
+}
+
+// the step that stores these rows has been enqueued: from now on the slots hold them (stream order puts any later copy
+// of a slot behind the store)
+static void cache_commit(ga3c_net* net, const int32_t* agents, const int64_t* seqs, int batch) {
+  std::lock_guard<std::mutex> g(net->cache_mu);
+  for (int i = 0; i < batch; ++i) {
+    const int ag = agents[i];
+    net->cache_tags[(size_t)ag * net->cache_depth + seqs[i] % net->cache_depth] = seqs[i];
+    if (seqs[i] > net->cache_newest[(size_t)ag]) net->cache_newest[(size_t)ag] = seqs[i];
+  }
 }
 
 static int predict_begin_common(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs, int32_t batch,
@@ -1954,6 +1975,7 @@ static int predict_begin_common(ga3c_net* net, const int64_t* offsets, const int
     // through the queue of its own, after a step that had long finished)
     rc = lane_forward(net, *L, batch, u8 ? STEP_GATHER_U8 : STEP_GATHER_F32, hp, hv);
     stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, now_ns() - t0);
+    if (rc == GA3C_OK && L->cache_on) cache_commit(net, agents, seqs, batch);
   }
   L->cache_on = false;
   if (rc != GA3C_OK) {
@@ -2266,12 +2288,14 @@ int ga3c_net_evaluate_frames(ga3c_net* net, const int32_t* agents, const int64_t
 // ---- state cache --------------------------------------------------------------------------------------------
 int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth) {
   if (!net) return fail(GA3C_EINVAL, "null argument");
-  if (max_agents < 1 || depth < 2) return fail(GA3C_EINVAL, "state cache: %d agents x %d states", max_agents, depth);
+  if (max_agents < 1 || depth < 2 * CACHE_SLACK) return fail(GA3C_EINVAL, "state cache: %d agents x %d states", max_agents, depth);
   HIPCHK(hipSetDevice(net->cfg.device));
   CHK(sync_all(net));
   std::lock_guard<std::mutex> g(net->cache_mu);
   if (net->cache_ring) (void)hipFree(net->cache_ring);
   net->cache_ring = nullptr;
+  net->cache_agents = net->cache_depth = 0;
+  net->stat[GA3C_STAT_STATE_CACHE_BYTES].store(0, std::memory_order_relaxed);
   const size_t bytes = (size_t)max_agents * depth * XS;
   if (hipMalloc((void**)&net->cache_ring, bytes) != hipSuccess) {
     (void)hipGetLastError();
@@ -2280,6 +2304,8 @@ int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth
   net->cache_agents = max_agents;
   net->cache_depth = depth;
   net->cache_newest.assign((size_t)max_agents, -1);
+  net->cache_tags.assign((size_t)max_agents * depth, -1);
+  net->stat[GA3C_STAT_STATE_CACHE_BYTES].store((int64_t)bytes, std::memory_order_relaxed);
   return GA3C_OK;
 }
 
@@ -2762,8 +2788,9 @@ int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int3
 
 int ga3c_net_stats(ga3c_net* net, int64_t* out, int32_t n, int32_t reset) {
   if (!net || !out || n < 0) return fail(GA3C_EINVAL, "bad argument");
-  for (int i = 0; i < n && i < GA3C_STAT_COUNT; ++i)
-    out[i] = reset ? net->stat[i].exchange(0, std::memory_order_relaxed) : net->stat[i].load(std::memory_order_relaxed);
+  for (int i = 0; i < n && i < GA3C_STAT_COUNT; ++i)      // (the cache's size is a gauge: a reset leaves it)
+    out[i] = (reset && i != GA3C_STAT_STATE_CACHE_BYTES) ? net->stat[i].exchange(0, std::memory_order_relaxed)
+                                                         : net->stat[i].load(std::memory_order_relaxed);
   for (int i = GA3C_STAT_COUNT; i < n; ++i) out[i] = 0;
   return GA3C_OK;
 }

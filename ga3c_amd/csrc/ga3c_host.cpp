@@ -659,6 +659,12 @@ int ga3c_shm_close(ga3c_shm* shm, int32_t unlink_segment) {
   return GA3C_H_OK;
 }
 
+int ga3c_shm_unlink(ga3c_shm* shm) {
+  if (!shm) return fail(GA3C_H_EINVAL, "null argument");
+  if (shm->owner) shm_unlink(shm->name.c_str());      // the name goes; mappings (ours, the agents', the GPU's) stay valid
+  return GA3C_H_OK;
+}
+
 int ga3c_shm_shutdown(ga3c_shm* shm) {
   if (!shm) return fail(GA3C_H_EINVAL, "null argument");
   Header* h = shm->hdr();

@@ -27,6 +27,7 @@ extern "C" {
 #define GA3C_EHIP (-2)     /* HIP runtime error */
 #define GA3C_ERCCL (-3)    /* RCCL error */
 #define GA3C_ESTATE (-4)   /* call not valid in this state */
+#define GA3C_ELOST (-5)    /* a row named by (agent, request number) is no longer in the state cache: the batch was not trained */
 
 #define GA3C_FLAG_LOG_SOFTMAX 1u   /* Config.USE_LOG_SOFTMAX branch, NetworkVP_discrate.py:64-71 */
 #define GA3C_FLAG_GRAD_CLIP 2u     /* Config.USE_GRAD_CLIP, tf.clip_by_average_norm, :120-123 */
@@ -185,9 +186,15 @@ int ga3c_net_train_gather(ga3c_net* net, const int64_t* offsets, int32_t u8, con
  * state (ga3c_pq_request_seq, include/ga3c_host.h) -- and lands in slot seqs[i] % depth of its agent.  A train batch then
  * names its rows the same way (ProcessAgent.py:88-100 ships the state itself; NetworkVP.py:254-257 feeds it) and is
  * gathered HBM to HBM: ga3c_net_train_cached / ga3c_net_evaluate_cached = ga3c_net_train_gather / ga3c_net_evaluate on
- * those rows, bit for bit.  A row whose request is not held (never stored, or more than `depth` requests of its agent
- * ago) is refused with GA3C_ESTATE.  uint8 states, plain launches (no GA3C_GRAPHS): up to 128 rows the conv stack stores
- * the bytes it stages, beyond that the gathered batch is filed by a copy kernel behind the gather. */
+ * those rows, bit for bit.  Every slot carries a tag, the request number it really holds, written once the step that stores
+ * the state has been enqueued: a row whose slot holds another request (never stored, its step failed, or overwritten since)
+ * or whose request is within 4 of falling out of its agent's window (a new prediction of that agent could overwrite it
+ * before the copy has run) is refused with GA3C_ELOST and nothing is trained -- the caller drops the batch (ThreadTrainer
+ * counts it).  `depth` is the caller's estimate of what an agent can have stored and not yet trained (Server.py: a multiple
+ * of the agents' fair share of the rollouts in flight, not the worst case of one agent owning them all: 28,224 B per state,
+ * 2.3 MB per agent at 80 states instead of 25 MB at 886); ga3c_net_stats reports the bytes held and the rows lost.  uint8
+ * states, plain launches (no GA3C_GRAPHS: a replayed launch has its arguments baked in, the slots travel in them): up to 128
+ * rows the conv stack stores the bytes it stages, beyond that the gathered batch is filed by a copy kernel behind the gather. */
 int ga3c_net_state_cache_config(ga3c_net* net, int32_t max_agents, int32_t depth);
 int ga3c_net_predict_gather_begin_cached(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const int64_t* seqs,
                                          int32_t batch, int32_t u8, int32_t* ticket);
@@ -267,6 +274,8 @@ enum {
   GA3C_STAT_TRAIN_READER_WAITS,    /* cross-stream waits a step issued for prediction lanes still reading the buffer it overwrites */
   GA3C_STAT_PREDICT_GPU_NS,        /* GPU span of a prediction step, first kernel's start to last kernel's end; collected only with
                                       GA3C_TIME_PREDICTIONS=1 in the environment (two timing events per step) */
+  GA3C_STAT_STATE_CACHE_BYTES,     /* gauge: bytes of HBM the state cache holds (0: none configured) */
+  GA3C_STAT_STATE_CACHE_LOST,      /* rows of train / evaluate batches that were refused with GA3C_ELOST */
   GA3C_STAT_COUNT
 };
 int ga3c_net_stats(ga3c_net* net, int64_t* out, int32_t n, int32_t reset);

@@ -76,6 +76,9 @@ int ga3c_shm_create(const char* name, const ga3c_shm_config* cfg, ga3c_shm** out
 int ga3c_shm_attach(const char* name, ga3c_shm** out);                              /* agent process */
 int ga3c_shm_close(ga3c_shm* shm, int32_t unlink_segment);
 int ga3c_shm_shutdown(ga3c_shm* shm);      /* wakes every waiter with GA3C_H_ECLOSED */
+/* Removes the segment's NAME (owner only) and leaves every mapping alone: for a server that must end without unmapping --
+ * the GPU may still be reading the registered segment -- and must not leave /dev/shm/ga3c_* behind. */
+int ga3c_shm_unlink(ga3c_shm* shm);
 void* ga3c_shm_base(ga3c_shm* shm);
 int64_t ga3c_shm_bytes(ga3c_shm* shm);
 int ga3c_shm_get_config(ga3c_shm* shm, ga3c_shm_config* cfg);

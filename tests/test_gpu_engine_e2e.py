@@ -160,8 +160,10 @@ def test_alternate_launch_paths_of_a_gathered_step_give_the_same_bits(monkeypatc
 def test_state_cache_keeps_what_predictions_read_and_trains_on_it_by_name():
     """ga3c_net_predict_gather_begin_cached stores the uint8 state of every row it reads in HBM (ring of `depth` per agent,
     slot = request number % depth); ga3c_net_train_cached / evaluate_cached on rows NAMED (agent, request number) must be
-    ga3c_net_train_gather / evaluate on the same bytes, bit for bit; a name that was never stored, or has been overwritten,
-    is refused."""
+    ga3c_net_train_gather / evaluate on the same bytes, bit for bit; a name that was never stored (a skipped request number:
+    the slot's tag says another request), has been overwritten, or is within 4 requests of falling out of its agent's window
+    is refused with GA3C_ELOST (nat.StateLost) and nothing is trained; ga3c_net_stats reports the cache's bytes and the rows
+    refused."""
     import ga3c_amd  # noqa: F401
     import _native as nat
     import Transport as tp
@@ -170,7 +172,7 @@ def test_state_cache_keeps_what_predictions_read_and_trains_on_it_by_name():
     t = tp.Transport.create(tp.unique_name("t_cache"), 40, 6, 84 * 84 * 4, 8, 8)
     net = Network("gpu:0", "cache", 6, (84, 84, 4), max_batch=64, predict_lanes=2)
     ref = Network("gpu:0", "cache_ref", 6, (84, 84, 4), max_batch=64, predict_lanes=1)
-    depth = 4
+    depth = 8
     try:
         net.register_transport(t)                          # (ref gets the same bytes through the host-buffer entry points:
         for n in (net, ref):                                # bit-identical to the zero-copy ones, tested above)
@@ -213,11 +215,27 @@ def test_state_cache_keeps_what_predictions_read_and_trains_on_it_by_name():
         net.train_frames(agents, seqs, y, a)
         ref.train(xs, y, a)
         assert np.array_equal(net.get_arena(0), ref.get_arena(0)) and np.array_equal(net.get_arena(1), ref.get_arena(1))
-        # names the cache does not hold
-        with pytest.raises(RuntimeError):
+        # names the cache does not hold: refused as LOST, and the weights stay as they are
+        assert net.stats()["state_cache_bytes"] == 40 * depth * 84 * 84 * 4 and net.stats()["state_cache_lost_rows"] == 0
+        before = net.get_arena(0)
+        with pytest.raises(nat.StateLost):
             net.train_frames(np.array([3], np.int32), np.array([22], np.int64), y[:1], a[:1])        # newer than the newest stored (21)
+        with pytest.raises(nat.StateLost):
+            net.train_frames(np.array([3, 3], np.int32), np.array([19, 17], np.int64), y[:2], a[:2])  # 17 was never stored: the
+        #                                                                                             slot's tag is -1, not 17
         with pytest.raises(RuntimeError):
             net.train_frames(np.array([40], np.int32), np.array([10], np.int64), y[:1], a[:1])       # no such agent
+        assert net.stats()["state_cache_lost_rows"] == 3 and np.array_equal(net.get_arena(0), before)
+        # agent 7 goes on predicting: request 31 of it is still held while fewer than depth - 4 newer ones exist, then lost --
+        # BEFORE its slot (31 % 8) is really overwritten by request 39
+        one = np.array([7], np.uint32)                      # (its requests so far: 31, 32, 33)
+        for sq, expect_held in ((34, True), (35, False)):
+            predict_named(one, np.array([sq], np.int64))
+            if expect_held:
+                net.evaluate(None, y[:1], a[:1], frames=(np.array([7], np.int32), np.array([31], np.int64)))
+            else:
+                with pytest.raises(nat.StateLost):
+                    net.evaluate(None, y[:1], a[:1], frames=(np.array([7], np.int32), np.array([31], np.int64)))
         t.agent_states[:] = rng.integers(0, 256, size=(40, 84 * 84 * 4), dtype=np.uint8)
         # a batch beyond the 192 offsets that travel in the kernel arguments (they are then read out of the pinned array)
         big = Network("gpu:0", "cache_big", 6, (84, 84, 4), max_batch=256, predict_lanes=1)

@@ -447,6 +447,27 @@ def test_an_answer_that_is_already_there_costs_no_wake_and_a_spinning_agent_sees
         t.close()
 
 
+def test_unlink_removes_the_name_and_keeps_the_mapping(mods):
+    """ga3c_shm_unlink: what a server does that must end without unmapping (a stalled data-parallel group, Server.shutdown):
+    /dev/shm holds no leftover, the segment stays usable for whoever has it mapped, an attached (non-owner) handle cannot
+    remove the name."""
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_unl"), 4, 6, 32, 2, 3)
+    try:
+        path = "/dev/shm" + t.name
+        assert os.path.exists(path)
+        other = tp.Transport.attach(t.name)
+        other.unlink()
+        assert os.path.exists(path)                         # not the owner
+        t.unlink()
+        assert not os.path.exists(path)
+        t.state_view(1)[:4] = 9                             # both mappings are alive and are the same memory
+        assert other.state_view(1)[:4].tolist() == [9, 9, 9, 9]
+        other.close()
+    finally:
+        t.close()
+
+
 def test_transport_many_threads_no_lost_or_duplicated_requests(mods):
     nat, tp, Config = mods
     n_agents, rounds = 24, 200

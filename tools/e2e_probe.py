@@ -120,7 +120,8 @@ def main():
               "train_reader_waits_per_call": round(eng.get("train_reader_waits", 0) / tc, 3),
               "train_rows_per_call": round(eng.get("train_rows", 0) / tc, 1)}
     print(json.dumps({
-        "placement": getattr(srv, "placement", None), "state_cache": bool(getattr(srv, "state_cache", False)), "lanes": args.lanes or args.predictors, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "engine": engine,
+        "placement": getattr(srv, "placement", None), "lost_train_batches": getattr(srv, "lost_train_batches", 0),
+        "state_cache_depth": getattr(srv, "state_cache_depth", None), "state_cache": bool(getattr(srv, "state_cache", False)), "lanes": args.lanes or args.predictors, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "engine": engine,
         "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / (b["t"] - a["t"]), 2), "throttled_periods": b["cg"][1] - a["cg"][1],
                    "throttled_s": round((b["cg"][2] - a["cg"][2]) / 1e6, 2)},
         "agents": args.agents, "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,

@@ -139,7 +139,8 @@ def main():
                 cpu["%s:%s" % (who, name)] = [round((u - u0) / dt, 2), round((k - k0) / dt, 2)]
     print(json.dumps({
         "cpu_cores_by_thread_name_user_sys": cpu, "us_cpu_per_prediction": round(sum(x + y for x, y in cpu.values()) * dt / max(pred, 1) * 1e6, 2),
-        "placement": getattr(srv, "placement", None), "engine": engine, "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / dt, 2), "throttled_periods": b["cg"][1] - a["cg"][1],
+        "placement": getattr(srv, "placement", None), "lost_train_batches": getattr(srv, "lost_train_batches", 0),
+        "state_cache_depth": getattr(srv, "state_cache_depth", None), "engine": engine, "cgroup": {"cpu_cores_used": round((b["cg"][0] - a["cg"][0]) / 1e6 / dt, 2), "throttled_periods": b["cg"][1] - a["cg"][1],
                                      "throttled_s": round((b["cg"][2] - a["cg"][2]) / 1e6, 2)},
         "agents": args.agents, "native_agents": True, "frame_queue_on_device": bool(args.frame_queue_on_device), "predictors": args.predictors, "trainers": args.trainers, "train": not args.no_train,
         "hogwild": bool(args.hogwild), "window_s": round(dt, 2), "host_cores": os.cpu_count(),
