@@ -87,7 +87,6 @@ struct Fwd {   // forward workspace of one lane (device pointers)
   float *x = nullptr, *n1 = nullptr, *n2 = nullptr, *part = nullptr, *d1 = nullptr, *z = nullptr, *p = nullptr,
         *v = nullptr;
   uint8_t* xu8 = nullptr;
-  unsigned* arrive = nullptr;   // dense1_heads_kernel: arrival counters of the 16-row tiles (zero between launches)
   bool x_u8 = false;   // the staged batch lives in xu8 (uint8 frames) and the conv kernels convert while reading
   // prediction intake fused into the conv stack: sample b lies src_off[b] bytes behind src_base (nullptr: dense batch)
   const uint8_t* src_base = nullptr;
@@ -286,7 +285,6 @@ struct ga3c_net {
   bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
   int wd_step_in_conv_bwd = 1;         // fused update: dense1/w stepped inside conv_bwd (GA3C_WD_STEP_IN_CONV_BWD: 0 never -- in
                                        // dense1_bwd_tile's epilogue --, 1 when conv_bwd's grid covers the 242 row groups, 2 always)
-  bool d1_heads = false;               // GA3C_D1_HEADS=1: dense1 forward + heads in one launch, last-arriving workgroup of a row tile.
                                        // Measured: 29 us against 5.7 + 5.8 us as two launches (profiles/README.md) -- kept for the record, off
   int d1f_frag_lanes = 2;              // prediction steps of >= 64 rows use the register-fragment dense1 (no LDS: it shares a CU
                                        // with another lane's conv stack, which the 148 KB tile kernel cannot) while at least
@@ -338,8 +336,6 @@ int alloc_fwd(Fwd& f, int maxB, int A) {
   CHK(dmalloc(&f.p, (size_t)maxB * A));
   CHK(dmalloc(&f.v, (size_t)maxB));
   HIPCHK(hipMalloc((void**)&f.xu8, (size_t)maxB * XS));
-  HIPCHK(hipMalloc((void**)&f.arrive, (size_t)(maxB / 16 + 1) * sizeof(unsigned)));
-  HIPCHK(hipMemset(f.arrive, 0, (size_t)(maxB / 16 + 1) * sizeof(unsigned)));
   return GA3C_OK;
 }
 
@@ -347,7 +343,6 @@ void free_fwd(Fwd& f) {
   for (float* p : {f.x, f.n1, f.n2, f.part, f.d1, f.z, f.p, f.v})
     if (p) (void)hipFree(p);
   if (f.xu8) (void)hipFree(f.xu8);
-  if (f.arrive) (void)hipFree(f.arrive);
 }
 
 bool is_pinned(const void* p) {
@@ -381,27 +376,6 @@ int launch_dense1_fwd(ga3c_net* net, const float* flat, const float* pk, float* 
   return GA3C_OK;
 }
 
-constexpr int D1H_MAX_DYN_LDS = 160 * 1024 - 256;
-// dense1 forward + heads in one launch (dense1_heads_kernel): where the LDS-tiled dense1 runs with 16-row tiles and A <= 8
-bool dense1_heads_fits(const ga3c_net* net, int B, int ks) {
-  const int max_steps = (KSTEPS_DENSE + ks - 1) / ks;
-  return net->d1_heads && net->d1f_tile && B <= 128 && net->A <= 8 && max_steps <= 16 && ks <= 22 &&
-         (size_t)d1f_lds_floats(1, max_steps) * sizeof(float) <= (size_t)D1H_MAX_DYN_LDS && dense1_fwd_blocks(B, ks, 1) <= 256;
-}
-
-int launch_dense1_heads(ga3c_net* net, const Fwd& f, const float* pk, const HeadArgs& h, int B, int ks, hipStream_t st, bool train,
-                        hipEvent_t e0, hipEvent_t e1) {
-  const int max_steps = (KSTEPS_DENSE + ks - 1) / ks;
-  const size_t lds = (size_t)d1f_lds_floats(1, max_steps) * sizeof(float);
-  const int blocks = dense1_fwd_blocks(B, ks, 1);
-  if (train)
-    hipExtLaunchKernelGGL((dense1_heads_kernel<true, 8>), dim3(blocks), dim3(512), lds, st, e0, e1, 0, f.n2, pk, f.part, B, ks, max_steps, h, f.arrive);
-  else
-    hipExtLaunchKernelGGL((dense1_heads_kernel<false, 8>), dim3(blocks), dim3(512), lds, st, e0, e1, 0, f.n2, pk, f.part, B, ks, max_steps, h, f.arrive);
-  HIPCHK(hipGetLastError());
-  (void)net;
-  return GA3C_OK;
-}
 
 constexpr int HEADS_WAVES = 1;   // samples (waves) per heads workgroup
 // ---- kernel launch helpers (shape checks live here: every grid is derived from B on the host)
@@ -449,11 +423,6 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
   h.log_softmax = (net->cfg.flags & GA3C_FLAG_LOG_SOFTMAX) ? 1 : 0;
   if (train) { h.y_r = tl->yr; h.act = tl->act; h.dz = tl->dz; h.dv = tl->dv; h.lossrow = tl->lossrow; h.dd1 = tl->dd1; h.beta = beta; }
-  if (dense1_heads_fits(net, B, ks)) {
-    CHK(launch_dense1_heads(net, f, net->theta_pk[idx], h, B, ks, st, train, nullptr, nullptr));
-    if (stop_ev) HIPCHK(hipEventRecord(stop_ev, st));
-    return GA3C_OK;
-  }
   // several prediction lanes at work: the fragment kernel (no LDS) runs beside the other lanes' conv stacks
   const bool frag = !train && !net->graphs && net->d1f_frag_lanes > 0 && B >= 64 &&
                     net->predict_inflight.load(std::memory_order_relaxed) >= net->d1f_frag_lanes;
@@ -1414,7 +1383,6 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
   if (const char* e = getenv("GA3C_D1F_FRAG_LANES")) net->d1f_frag_lanes = atoi(e);
-  if (const char* e = getenv("GA3C_D1_HEADS")) net->d1_heads = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
@@ -1431,11 +1399,10 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
       return fail(GA3C_EHIP, "cannot reserve LDS for conv_bwd_kernel: %s", hipGetErrorString(e));
     }
   }
-  const void* d1f_fns[4] = {reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<1>), reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<2>),
-                            reinterpret_cast<const void*>(&dense1_heads_kernel<false, 8>), reinterpret_cast<const void*>(&dense1_heads_kernel<true, 8>)};
-  for (int i = 0; i < 4; ++i) {
+  const void* d1f_fns[2] = {reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<1>), reinterpret_cast<const void*>(&dense1_fwd_tile_kernel<2>)};
+  for (int i = 0; i < 2; ++i) {
     const void* fn = d1f_fns[i];
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, i < 2 ? 160 * 1024 : D1H_MAX_DYN_LDS);   // the fused kernel has a static word too
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       delete net;
       return fail(GA3C_EHIP, "cannot reserve LDS for dense1_fwd_tile_kernel: %s", hipGetErrorString(e));
@@ -2634,16 +2601,6 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       const int rc = launch_dense1_fwd(net, t.f.n2, net->theta_pk[net->latest], t.f.part, B, dense_ks(B), t.st, t.ev0, t.ev1);
       net->d1f_tile = keep;
       CHK(rc);
-    } else if (k == "dense1_heads") {
-      HeadArgs h;
-      memset(&h, 0, sizeof h);
-      const int ks = dense_ks(B);
-      if (!dense1_heads_fits(net, B, ks)) return fail(GA3C_EINVAL, "dense1_heads does not run at this batch / action count");
-      h.part = t.f.part; h.ks = ks; h.B = B; h.A = net->A;
-      h.bd = th + OFF_BD; h.wv = th + OFF_WV; h.bv = th + OFF_BV; h.wp = th + OFF_WP; h.bp = th + off_bp(net->A);
-      h.d1 = t.f.d1; h.z = t.f.z; h.p = t.f.p; h.v = t.f.v;
-      h.log_eps = net->cfg.log_epsilon; h.min_policy = net->cfg.min_policy;
-      CHK(launch_dense1_heads(net, t.f, net->theta_pk[net->latest], h, B, ks, t.st, false, t.ev0, t.ev1));
     } else if (k == "conv1_dw") {
       TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {

@@ -955,70 +955,6 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadArgs h) {
   heads_rows<TRAIN, AMAX, 1>(h, rows, threadIdx.x & 63);
 }
 
-// ---- dense1 forward + heads in ONE launch: dense1_fwd_tile_kernel<1>'s workgroups, and the LAST of the 2*ks workgroups of
-// a 16-row tile to arrive (device-scope counter behind a release fence) runs heads for those rows (two per wave), reading
-// the slabs in slice order exactly as heads_kernel does: same bits.  No workgroup waits for another.
-template <bool TRAIN, int AMAX>
-__global__ __launch_bounds__(512) void dense1_heads_kernel(const float* __restrict__ flat, const float* __restrict__ pk,
-                                                           float* part, int B, int ks_total, int max_steps, HeadArgs h,
-                                                           unsigned* arrive) {
-  extern __shared__ __attribute__((aligned(16))) float d1f_lds[];
-  __shared__ int is_last;
-  float* wls = d1f_lds;                                    // [step][8 column tiles][16 n][16 kk]
-  float* als = d1f_lds + max_steps * 8 * 256;              // [16 rows][260]
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int nrow = (B + 15) / 16;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int rb = j % nrow, yz = (j / nrow) * 8 + xcd;      // yz = ks * 2 + column half (blocks of one slice share an XCD)
-  if (yz >= ks_total * 2) return;                          // block-uniform; such blocks are not counted below
-  const int m0 = rb * 16, ks = yz >> 1, half = yz & 1;
-  const int s0 = (ks * KSTEPS_DENSE) / ks_total, s1 = ((ks + 1) * KSTEPS_DENSE) / ks_total, steps = s1 - s0;
-  for (int p = wv; p < steps * 8; p += 8) {
-    const int sl = p >> 3, nt = p & 7;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pk + ((size_t)(s0 + sl) * HID + half * 128 + nt * 16) * 16 + 4 * lane),
-                                     (__attribute__((address_space(3))) void*)(wls + p * 256), 16, 0, 0);
-  }
-  for (int row = wv; row < 16; row += 8) {
-    if (m0 + row < B) {                                     // wave-uniform
-      if (4 * lane < 16 * steps)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(flat + (size_t)(m0 + row) * FLAT + 16 * s0 + 4 * lane),
-                                         (__attribute__((address_space(3))) void*)(als + row * D1F_AS), 16, 0, 0);
-    } else {
-      *reinterpret_cast<f32x4*>(&als[row * D1F_AS + 4 * lane]) = zero4();
-    }
-  }
-  __syncthreads();                                           // vmcnt(0) precedes the barrier: the DMA has landed
-  f32x4 acc[2] = {zero4(), zero4()};
-  const float* bp = wls + (wv * 16 + r) * 16 + 4 * g;
-  const float* ap = als + r * D1F_AS + 4 * g;
-  for (int sl = 0; sl < steps; ++sl) {
-    const f32x4 w = ld4(bp + sl * 8 * 256);
-    const f32x4 a = ld4(ap + 16 * sl);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t & 1] = mfma(a[t], w[t], acc[t & 1]);
-  }
-  float* out = part + ((size_t)ks * B) * HID + half * 128 + wv * 16 + r;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int mr = m0 + 4 * g + q;
-    if (mr < B) out[(size_t)mr * HID] = acc[0][q] + acc[1][q];
-  }
-  // ---- the seam: slabs out (barrier: every wave's stores are issued and complete), one release fence and one arrival
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this XCD's L2 -> memory: the slabs are visible device-wide
-    const unsigned old = __hip_atomic_fetch_add(&arrive[rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = old == (unsigned)(2 * ks_total - 1);
-    if (is_last) arrive[rb] = 0;                             // the next launch on this lane starts from zero (stream order)
-  }
-  __syncthreads();
-  if (!is_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // the other workgroups' slabs came through other XCDs' L2s
-  const int r0 = m0 + wv, r1 = m0 + wv + 8;
-  const int rows[2] = {r0 < B ? r0 : -1, r1 < B ? r1 : -1};
-  heads_rows<TRAIN, AMAX, 2>(h, rows, lane);
-}
-
 // ------------------------------------------------------------------ heads backward (weight gradients)
 // Runs as extra blocks of dense1_dw_kernel (no launch of its own):
 // role o in [0,A]: dW[k] = sum_b d1[b][k] dhead[b] (o<A: dWp[:,o], dbp[o]; o==A: dWv, dbv), LDS fold, fixed order

@@ -530,11 +530,22 @@ def test_engine_at_the_agent_counts_of_baseline_configs_3_and_4(tmp_path, monkey
         pps, tps, batch = (pb - pa) / (tb - ta), (sb_ - sa) / (tb - ta), (pb - pa) / max(bb - ba, 1)
         stats = srv.model.stats()
         srv.model.close()
-        # measured on one MI355X box with a 16-core quota (tools/engine_ceiling.py, 10-s runs): 495-550 k predictions/s,
-        # 3.8-4.3 k train steps/s, 19-109-row batches; inside the whole suite, 8-s runs right behind other engine tests,
-        # as low as 240 k / 1.8 k / 9 rows.  The floors mark a collapse (58-67 k predictions/s in round 2's CAS-loop ring),
-        # not a performance target
-        assert pps > 100e3 and tps > 700 and batch > 4, (pps, tps, batch)
+
+        def cgroup():
+            try:
+                return dict(line.split()[:2] for line in open("/sys/fs/cgroup/cpu.stat"))
+            except OSError:
+                return {}
+        # Round 3 saw this test at 240 k predictions/s inside the suite against 495-550 k alone and lowered its floors to
+        # 100 k "right behind other engine tests".  The cause, found in round 4 (profiles/r04_engine_matrix.md): hundreds of
+        # agent threads free to roam the host's 256 CPUs -- every wake on a cold idle core, 38 us of CPU per prediction, the
+        # cgroup's 16-CPU quota spent and the whole process throttled in every period: 120-400 k from run to run of the SAME
+        # command.  The server now places itself on L3 domains next to the GPU (Placement.py): 7.5 us per prediction, no
+        # throttling, 0.74-1.03 M predictions/s and 5.7-7.9 k train steps/s at 256 / 512 agents, run after run.  The floors are
+        # back at half of that; the message carries what would explain a miss.
+        where = srv.placement["why"] if srv.placement else "unplaced"
+        assert pps > 350e3 and tps > 2500 and batch > 8, (pps, tps, batch, where, cgroup(), out.get("tool"), srv.lost_train_batches)
+        assert srv.lost_train_batches == 0                        # the state cache held every named row
         assert stats["predict_weight_waits"] == 0                 # predictions never wait for a step in flight
         assert stats["train_rows"] / max(stats["train_calls"], 1) > 127
         assert all(t.is_alive() is False for t in srv.predictors + srv.trainers) and srv.failure is None

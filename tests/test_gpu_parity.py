@@ -305,31 +305,6 @@ def test_large_batch_and_u8_train_path(nets):
     assert np.max(np.abs(g_all - (g_lo + g_hi))) < 1e-4 * max(1.0, np.max(np.abs(g_all)))
 
 
-def test_dense1_heads_single_launch_same_bits(nets, monkeypatch):
-    """GA3C_D1_HEADS=1: dense1 forward + heads in one launch (the last-arriving workgroup of a 16-row tile runs the heads).
-    Off by default because it is slower (profiles/README.md); it must give the bits of the two launches."""
-    import ga3c_amd  # noqa: F401
-    from NetworkVP import Network
-    ref = nets(6)
-    monkeypatch.setenv("GA3C_D1_HEADS", "1")
-    net = Network("gpu:0", "test_d1h", 6, (84, 84, 4), max_batch=160, predict_lanes=2)
-    monkeypatch.delenv("GA3C_D1_HEADS")
-    try:
-        for n in (net, ref):
-            n.set_arena(0, _flat(o.init_params(6), 6))
-            n.set_arena(1, np.ones(n.param_count, np.float32))
-            n.learning_rate, n.beta = 3e-4, 0.01
-        for B in (1, 17, 100, 128, 131):            # 131: beyond the fused kernel's range, the two launches run
-            _, x, a, y = _batch(B, 6, 700 + B)
-            for _ in range(3):                      # the arrival counters must be back at zero after every launch
-                got, want = net.predict_p_v_logits(x), ref.predict_p_v_logits(x)
-                assert all(np.array_equal(g, w) for g, w in zip(got, want))
-            assert np.array_equal(np.asarray(net.train(x, y, a)), np.asarray(ref.train(x, y, a)))
-            assert np.array_equal(net.get_arena(0), ref.get_arena(0))
-    finally:
-        net.close()
-
-
 def test_dense1_fragment_and_tile_kernels_give_the_same_bits(nets, monkeypatch):
     """The engine picks dense1's register-fragment kernel (no LDS) for prediction steps while two or more lanes are at work,
     the LDS-tiled one otherwise: the choice depends on timing, so the two must agree bit for bit (same split-K slices, same
