@@ -98,6 +98,23 @@ class ProcessAgent(MP.Process):
             if rc == tp.CLOSED or self.exit_flag.value:
                 raise SystemExit(0)
 
+    def predict_and_select(self, state, flags=0):
+        """predict() + select_action() of one step in ONE foreign call (ga3c_pq_round_trip): state (or raw frame) into the
+        slot, submit, wait, draw.  The uniform comes from the global RandomState exactly where np.random.choice would draw
+        it -- one draw per step, none in PLAY_MODE (ProcessAgent.py:102-115) -- so seeds give the reference's actions.
+        -> (prediction, value, action)."""
+        u = -1.0 if Config.PLAY_MODE else np.random.random_sample()
+        flat = state.reshape(-1)
+        rc, p, v, a = self.transport.round_trip(self.id, flat if flat.flags.c_contiguous else np.ascontiguousarray(flat),
+                                                flags, Config.QUEUE_TIMEOUT_MS, u)
+        if rc == tp.CLOSED:                                 # nothing was queued
+            raise SystemExit(0)
+        while rc != 0:
+            if rc == tp.CLOSED or self.exit_flag.value:
+                raise SystemExit(0)
+            rc, p, v, a = self.transport.round_trip(self.id, None, flags, Config.QUEUE_TIMEOUT_MS, u, submit=False)
+        return p, v, int(self.actions[a]) if a >= 0 else int(np.argmax(p))
+
     def push_frame(self, frame, flags):
         """Device front-end: the raw frame goes into this agent's slot; the answer is (p, v) of the state the frame
         completed (meaningless when flags ask for no prediction)."""
@@ -141,8 +158,8 @@ class ProcessAgent(MP.Process):
                 self.env.step(None)             # frame queue still filling (ProcessAgent.py:127-129)
                 continue
             state = self.env.current_u8 if as_u8 else self.env.current_state
-            prediction, value = self.predict(state)
-            action = self.select_action(self.actions, prediction)
+            prediction, value, action = self.predict_and_select(state)
+            self.requests += 1                                  # = this request's number (ga3c_pq_request_seq)
             reward, done = self.env.step(action)
             reward_sum += reward
             if self.names_states:               # the engine kept the state this request carried: the experience names it
@@ -174,13 +191,15 @@ class ProcessAgent(MP.Process):
         flags = tp.REQ_RESET
         while not done:
             full = env.frames_queued >= env.nb_frames
-            prediction, value = self.push_frame(env.frame, flags | (0 if full else tp.REQ_NO_PREDICT))
-            flags = 0
-            if not full:
-                env.step(None)                  # frame queue still filling (ProcessAgent.py:127-129)
+            if not full:                        # frame queue still filling (ProcessAgent.py:127-129): push only, no draw
+                self.push_frame(env.frame, flags | tp.REQ_NO_PREDICT)
+                flags = 0
+                env.step(None)
                 continue
+            prediction, value, action = self.predict_and_select(env.frame, flags)
+            self.planes_pushed += 1
+            flags = 0
             state = self.planes_pushed - 1      # the state is named by its newest plane
-            action = self.select_action(self.actions, prediction)
             reward, done = env.step(action)
             reward_sum += reward
             experiences.append(Experience(state, action, prediction, reward, None, done))

@@ -36,6 +36,8 @@ class Transport:
                                                             strides=(stride, 1), writeable=True)
         self._views = {}
         self._vcells = {}
+        self._rcells = {}
+        self._round_trip = self._lib.ga3c_pq_round_trip
         self._submit = self._lib.ga3c_pq_submit_flags
         # the same entry point with untyped pointer arguments: an address or a byref() goes through without a POINTER object
         self._wait = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32)(("ga3c_pq_wait", self._lib))
@@ -87,6 +89,23 @@ class Transport:
     def submit(self, agent, flags=0):
         rc = self._submit(self._h, agent, flags)
         return rc if rc in (0, TIMEOUT, CLOSED) else nat.check_host(rc, "ga3c_pq_submit_flags")
+
+    def round_trip(self, agent, state, flags, timeout_ms, u, submit=True):
+        """One agent step's conversation with the predictor in one foreign call (ga3c_pq_round_trip): `state` (a contiguous
+        array, or None when the slot was filled in place) into the slot, submit, wait, draw the action for uniform `u`
+        (u < 0: no draw).  -> (rc, p, v, action index); rc = TIMEOUT leaves the request in flight: call again with
+        submit=False."""
+        p = np.empty(self.num_actions, np.float32)
+        cell = self._rcells.get(agent)
+        if cell is None:
+            v, a = C.c_float(), C.c_int32()
+            cell = self._rcells[agent] = (v, C.addressof(v), a, C.addressof(a))
+        rc = self._round_trip(self._h, agent, state.ctypes.data if state is not None else None,
+                              state.nbytes if state is not None else 0, flags, 1 if submit else 0, timeout_ms, u,
+                              p.ctypes.data, cell[1], cell[3])
+        if rc not in (0, TIMEOUT, CLOSED):
+            nat.check_host(rc, "ga3c_pq_round_trip")
+        return rc, p, cell[0].value, cell[2].value
 
     def request_flags(self, ids):
         out = np.empty(ids.size, np.uint32)

@@ -774,6 +774,23 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
   return GA3C_H_OK;
 }
 
+int ga3c_pq_round_trip(ga3c_shm* shm, int32_t agent, const void* state, int32_t state_bytes, uint32_t flags, int32_t submit,
+                       int32_t timeout_ms, double u, float* p, float* v, int32_t* action) {
+  if (!shm || !p || !v || agent < 0 || agent >= shm->hdr()->cfg.max_agents) return fail(GA3C_H_EINVAL, "bad argument");
+  if (submit) {
+    if (state) {
+      if (state_bytes < 0 || state_bytes > shm->hdr()->cfg.state_bytes) return fail(GA3C_H_EINVAL, "state of %d bytes does not fit the slot", state_bytes);
+      memcpy(shm->base + shm->hdr()->agents_off + agent * shm->hdr()->agent_stride, state, (size_t)state_bytes);
+    }
+    const int rc = ga3c_pq_submit_flags(shm, agent, flags);
+    if (rc != GA3C_H_OK) return rc;
+  }
+  const int rc = ga3c_pq_wait(shm, agent, p, v, timeout_ms);
+  if (rc != GA3C_H_OK) return rc;
+  if (action) *action = u >= 0.0 ? ga3c_select_action(p, shm->hdr()->cfg.num_actions, u) : -1;
+  return GA3C_H_OK;
+}
+
 int ga3c_pq_set_spin(ga3c_shm* shm, int32_t spin_us) {
   if (!shm || spin_us < 0) return fail(GA3C_H_EINVAL, "bad argument");
   shm->hdr()->spin_us.store(spin_us, std::memory_order_relaxed);

@@ -98,6 +98,13 @@ int ga3c_pq_submit(ga3c_shm* shm, int32_t agent);
 int ga3c_pq_submit_flags(ga3c_shm* shm, int32_t agent, uint32_t flags);
 int ga3c_pq_request_flags(ga3c_shm* shm, const uint32_t* ids, int32_t n, uint32_t* flags);   /* predictor side */
 int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeout_ms);
+/* One agent step's whole conversation with the predictor in ONE call (ProcessAgent.py:102-115: put, get, select_action):
+ * `submit` != 0: copy `state` (state_bytes; NULL: the slot was filled in place) into the agent's slot and submit it with
+ * `flags`; then wait up to timeout_ms for (p, v); then, with u >= 0, draw the action as ga3c_select_action(p, n, u) into
+ * *action (u < 0: -1, the caller decides -- PLAY_MODE's argmax).  GA3C_H_ETIMEOUT leaves the request in flight: call again
+ * with submit = 0 to go on waiting.  For an interpreted host this is one foreign call per step instead of four. */
+int ga3c_pq_round_trip(ga3c_shm* shm, int32_t agent, const void* state, int32_t state_bytes, uint32_t flags, int32_t submit,
+                       int32_t timeout_ms, double u, float* p, float* v, int32_t* action);
 /* How long ga3c_pq_wait polls for the answer before the agent announces its sleep and waits on the slot's futex (0 = not at
  * all, the default: a GPU round trip is 60 us and more, and a polling agent holds a core).  An answer that arrives while the
  * agent is still awake costs neither side a system call: ga3c_pq_respond wakes only agents that have announced their sleep.
