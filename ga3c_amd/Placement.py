@@ -157,14 +157,22 @@ def apply(cpus):
     return moved
 
 
+_applied = None      # what place() did to this process last (a second Server of the process finds itself placed already)
+
+
 def place(setting="auto", device=0):
     """Config.CPU_AFFINITY -> the CPUs chosen (None when nothing was changed)."""
+    global _applied
     if setting is None or setting is False or setting in ("", "off"):
         return None
+    if _applied is not None and set(_applied.get("server_cpus", _applied["cpus"])) == os.sched_getaffinity(0) and \
+            _applied.get("setting") == (setting, int(device)):
+        return _applied
     if setting != "auto":
         cpus = parse_cpulist(setting)
         apply(cpus)
-        return {"cpus": cpus, "why": "Config.CPU_AFFINITY = %r" % (setting,)}
+        _applied = {"cpus": cpus, "why": "Config.CPU_AFFINITY = %r" % (setting,), "setting": (setting, int(device))}
+        return _applied
     import ctypes as C
     import _native as nat
     bus = None
@@ -179,5 +187,7 @@ def place(setting="auto", device=0):
             apply(got["server_cpus"])
         else:
             apply(got["cpus"])
+        got["setting"] = (setting, int(device))
+        _applied = got
         return got
     return None

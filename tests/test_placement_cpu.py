@@ -93,6 +93,7 @@ def test_place_applies_an_explicit_list_and_can_be_switched_off():
         one = sorted(before)[:1]
         got = Placement.place(",".join(str(c) for c in one))
         assert got["cpus"] == one and os.sched_getaffinity(0) == set(one)
+        assert Placement.place(",".join(str(c) for c in one)) is got       # a second Server of the process: placed already
     finally:
         Placement.apply(before)
     assert os.sched_getaffinity(0) == before
