@@ -119,10 +119,18 @@ int main(int argc, char** argv) {
       float p[6], v;
       for (int k = 0; k < rounds; ++k) {
         const int tag = a * 100000 + k;
-        std::memcpy(ga3c_pq_state_ptr(shm, a), &tag, 4);
-        REQUIRE(ga3c_pq_submit(shm, a) == 0);
         int rc;
-        while ((rc = ga3c_pq_wait(shm, a, p, &v, 100)) == GA3C_H_ETIMEOUT) {}
+        if ((a + k) % 3 == 0) {                 // the three calls of ProcessAgent.predict one by one ...
+          std::memcpy(ga3c_pq_state_ptr(shm, a), &tag, 4);
+          REQUIRE(ga3c_pq_submit(shm, a) == 0);
+          while ((rc = ga3c_pq_wait(shm, a, p, &v, 100)) == GA3C_H_ETIMEOUT) {}
+        } else {                                // ... or the whole step in one call (ga3c_pq_round_trip), with and without a draw
+          int32_t action = -7;
+          const double u = (a + k) % 3 == 1 ? 0.999999 : -1.0;
+          rc = ga3c_pq_round_trip(shm, a, &tag, 4, 0, 1, 100, u, p, &v, &action);
+          while (rc == GA3C_H_ETIMEOUT) rc = ga3c_pq_round_trip(shm, a, nullptr, 0, 0, 0, 100, u, p, &v, &action);
+          if (rc == 0) REQUIRE(u < 0 ? action == -1 : (action >= 0 && action < 6));
+        }
         REQUIRE(rc == 0);
         REQUIRE((int)v == tag);
         REQUIRE((int)p[2] == tag % 7 + 2);
@@ -137,6 +145,7 @@ int main(int argc, char** argv) {
         }
       }
     });
+  if (n_agents > 1) ga3c_pq_set_spin(shm, 20);     // agents 0.. poll briefly before they announce their sleep (the waiter flag's other path)
   for (auto& t : agents) t.join();
   while (trained_rows.load() < produced_rows.load()) std::this_thread::yield();
   ga3c_shm_shutdown(shm);

@@ -447,6 +447,49 @@ def test_an_answer_that_is_already_there_costs_no_wake_and_a_spinning_agent_sees
         t.close()
 
 
+def test_round_trip_is_predict_plus_select_action_in_one_call(mods):
+    """ga3c_pq_round_trip (ProcessAgent.predict_and_select): the state lands in the agent's slot, the request is queued once,
+    the answer comes back with the action np.random.choice would draw for the uniform passed in; a timeout leaves the request
+    in flight and a second call (submit = False) collects it; u < 0 draws nothing."""
+    import threading
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_rt"), 4, 6, 64, 2, 3)
+    ids = np.zeros(8, np.uint32)
+    try:
+        state = np.arange(64, dtype=np.uint8)
+        pvec = np.array([0.1, 0.2, 0.3, 0.15, 0.15, 0.1], np.float32)
+        got = {}
+
+        def agent(u):
+            got["r"] = t.round_trip(3, state, 0, 2000, u)
+
+        for u, want in ((0.05, 0), (0.35, 2), (0.999, 5), (-1.0, -1)):
+            th = threading.Thread(target=agent, args=(u,))
+            th.start()
+            assert t.pop_batch(ids, 1000) == 1 and ids[0] == 3
+            assert t.state_view(3)[:64].tolist() == state.tolist()
+            t.respond(ids, 1, pvec, np.array([0.5], np.float32))
+            th.join(5)
+            rc, p, v, a = got["r"]
+            assert rc == 0 and v == 0.5 and p.tolist() == pvec.tolist() and a == want
+            if u >= 0:
+                assert a == tp.select_action_index(pvec, u)
+        # nobody answers in time: TIMEOUT, the request stays queued; then the answer is collected without a second submit
+        rc, _, _, _ = t.round_trip(3, state, 0, 20, 0.5)
+        assert rc == tp.TIMEOUT and not t.agent_idle(3)
+        assert t.pop_batch(ids, 100) == 1 and t.pop_batch(ids, 10) == 0       # queued exactly once
+        t.respond(ids, 1, pvec, np.array([1.5], np.float32))
+        rc, p, v, a = t.round_trip(3, None, 0, 100, 0.5, submit=False)
+        assert rc == 0 and v == 1.5 and a == 2 and t.agent_idle(3)
+        big = np.zeros(t.state_bytes + 16, np.uint8)
+        with pytest.raises(RuntimeError):
+            t.round_trip(3, big, 0, 10, 0.5)                                   # does not fit the slot: nothing is queued
+        assert t.agent_idle(3)
+    finally:
+        t.shutdown()
+        t.close()
+
+
 def test_unlink_removes_the_name_and_keeps_the_mapping(mods):
     """ga3c_shm_unlink: what a server does that must end without unmapping (a stalled data-parallel group, Server.shutdown):
     /dev/shm holds no leftover, the segment stays usable for whoever has it mapped, an attached (non-owner) handle cannot
