@@ -70,6 +70,54 @@ int fail(int code, const char* fmt, ...) {
     if (_r != GA3C_OK) return _r; \
   } while (0)
 
+// HIP streams of the process, kept for its lifetime and lent to the networks that live in it.  The runtime multiplexes the
+// streams of a process onto four hardware queues per priority and gives a new stream whichever queue it counts least used;
+// those counts do not go back to where they were when streams are destroyed, so where the streams of a SECOND network of the
+// process land depends on the networks before it.  Measured with bench.py (round 4): behind the kernel-timing, Hogwild and
+// data-parallel networks of its earlier legs the engine legs ran at 261 / 290 / 295 k predictions/s (the server's two
+// prediction lanes no longer on queues of their own) against 320 / 517 / 516 k when the earlier networks happened to create an
+// even number of streams, and against 318 k for the same server as the process's first network.  Streams are therefore
+// created once, in a fresh process's order, and re-used: a network takes the first free stream of the priority it asks for
+// and hands it back when it is destroyed (networks alive at the same time -- GA3C_mixed.py -- never share one).
+struct PooledStream { hipStream_t st; int device; bool high; bool busy; };
+std::mutex g_stream_mu;
+std::vector<PooledStream> g_streams;
+
+hipError_t stream_take(int device, bool high_priority, hipStream_t* out) {
+  std::lock_guard<std::mutex> g(g_stream_mu);
+  for (PooledStream& p : g_streams)
+    if (!p.busy && p.device == device && p.high == high_priority) {
+      p.busy = true;
+      *out = p.st;
+      return hipSuccess;
+    }
+  hipStream_t st = nullptr;
+  hipError_t e;
+  if (high_priority) {
+    int lo = 0, hi = 0;
+    e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi);
+  } else {
+    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  }
+  if (e != hipSuccess) return e;
+  g_streams.push_back({st, device, high_priority, true});
+  *out = st;
+  return hipSuccess;
+}
+
+void stream_give_back(hipStream_t st) {
+  if (!st) return;
+  (void)hipStreamSynchronize(st);                    // nothing of the old owner is left on it
+  std::lock_guard<std::mutex> g(g_stream_mu);
+  for (PooledStream& p : g_streams)
+    if (p.st == st) {
+      p.busy = false;
+      return;
+    }
+  (void)hipStreamDestroy(st);                         // not one of ours
+}
+
 // rocTX ranges around the engine's calls (tracing): `rocprofv3 --marker-trace` shows ga3c.predict /
 // ga3c.train.stage / ga3c.train.step on the host timeline beside the kernels; a no-op without a profiler attached
 struct TraceRange {
@@ -917,7 +965,7 @@ void free_frames(Frames& f) {
   if (f.h_slot) (void)hipHostFree(f.h_slot);
   if (f.ring) (void)hipFree(f.ring);
   f.h_src = nullptr; f.h_slot = nullptr; f.ring = nullptr; f.hist = 0;
-  if (f.st) (void)hipStreamDestroy(f.st);
+  if (f.st) stream_give_back(f.st);
   f.d_tab = nullptr; f.stacks = nullptr; f.d_rgb = f.h_rgb = f.d_planes = f.h_planes = f.h_reset = nullptr;
   f.h_agents = nullptr; f.st = nullptr; f.on = false;
 }
@@ -1194,10 +1242,9 @@ int alloc_train_lane(ga3c_net* net, TrainLane& t, float* shared_grad) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     const bool plain = getenv("GA3C_TRAIN_PRIORITY") && atoi(getenv("GA3C_TRAIN_PRIORITY")) == 0;
-    if (plain) HIPCHK(hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking));
-    else HIPCHK(hipStreamCreateWithPriority(&t.st, hipStreamNonBlocking, hi));
+    HIPCHK(stream_take(net->cfg.device, !plain, &t.st));
   }
-  HIPCHK(hipStreamCreateWithFlags(&t.gst, hipStreamNonBlocking));
+  HIPCHK(stream_take(net->cfg.device, false, &t.gst));
   CHK(alloc_fwd(t.f, maxB, A));
   for (int k = 0; k < 2; ++k) {
     Intake& in = t.in[k];
@@ -1265,10 +1312,10 @@ void free_train_lane(TrainLane& t) {
     if (p) (void)hipFree(p);
   if (t.owns_grad && t.grad) (void)hipFree(t.grad);
   if (t.h_out) (void)hipHostFree(t.h_out);
-  if (t.gst) (void)hipStreamDestroy(t.gst);
+  if (t.gst) stream_give_back(t.gst);
   if (t.ev0) (void)hipEventDestroy(t.ev0);
   if (t.ev1) (void)hipEventDestroy(t.ev1);
-  if (t.st) (void)hipStreamDestroy(t.st);
+  if (t.st) stream_give_back(t.st);
 }
 
 int sync_all(ga3c_net* net) {
@@ -1492,7 +1539,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     net->lanes.push_back(L);
     L->sidx = i % net->lane_streams;
     if (i < net->lane_streams) {
-      TRYHIP(hipStreamCreateWithFlags(&L->st, hipStreamNonBlocking));
+      TRYHIP(stream_take(cfg->device, false, &L->st));
     } else {
       Lane* host = net->lanes[(size_t)(i % net->lane_streams)];
       L->st = host->st;
@@ -1530,7 +1577,7 @@ int ga3c_net_destroy(ga3c_net* net) {
   (void)hipDeviceSynchronize();
   if (net->cache_ring) (void)hipFree(net->cache_ring);
   if (net->comm) (void)ncclCommDestroy(net->comm);
-  if (net->cst) (void)hipStreamDestroy(net->cst);
+  if (net->cst) stream_give_back(net->cst);
   for (hipEvent_t e : {net->ev_tail_ready, net->ev_head_ready, net->ev_comm_done})
     if (e) (void)hipEventDestroy(e);
   for (Lane* L : net->lanes) {
@@ -1542,7 +1589,7 @@ int ga3c_net_destroy(ga3c_net* net) {
     if (L->cache_dst) (void)hipHostFree(L->cache_dst);
     for (hipEvent_t e : {L->done, L->tm0, L->tm1})
       if (e) (void)hipEventDestroy(e);
-    if (L->st && L->owns_st) (void)hipStreamDestroy(L->st);
+    if (L->st && L->owns_st) stream_give_back(L->st);
     delete L;
   }
   free_train_lane(net->tr);
@@ -2047,7 +2094,7 @@ int ga3c_net_frames_config(ga3c_net* net, int32_t max_agents, int32_t height, in
   HIPCHK(hipHostMalloc((void**)&f.h_slot, (size_t)max_agents * sizeof(int32_t), hipHostMallocDefault));
   f.hist = history;
   if (history) HIPCHK(hipMalloc((void**)&f.ring, (size_t)max_agents * history * IMG * IMG));
-  HIPCHK(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
+  HIPCHK(stream_take(net->cfg.device, false, &f.st));
   f.filled.assign((size_t)max_agents, 0);
   f.pushed.assign((size_t)max_agents, 0);
   f.on = true;
@@ -2737,7 +2784,7 @@ int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int3
   net->world = world;
   net->rank = rank;
   net->comm_overlap = !(getenv("GA3C_COMM_OVERLAP") && atoi(getenv("GA3C_COMM_OVERLAP")) == 0);
-  HIPCHK(hipStreamCreateWithFlags(&net->cst, hipStreamNonBlocking));
+  HIPCHK(stream_take(net->cfg.device, false, &net->cst));
   for (hipEvent_t* e : {&net->ev_tail_ready, &net->ev_head_ready, &net->ev_comm_done})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   return GA3C_OK;
