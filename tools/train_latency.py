@@ -63,7 +63,7 @@ cnet = Network("gpu:0", "tlat_cache", 6, (84, 84, 4), max_batch=160, predict_lan
 net.unregister_transport()
 cnet.register_transport(t)
 cnet.learning_rate, cnet.beta = 3e-4, 0.01
-cnet.state_cache_config(160, 4)
+cnet.state_cache_config(160, 8)
 for lo in (0, 80):
     ids_ = np.arange(lo, lo + 80, dtype=np.uint32)
     offs_ = np.ascontiguousarray(t.state_offsets(ids_), dtype=np.int64)
