@@ -234,23 +234,19 @@ def main():
         device_sync()
         t1 = time.perf_counter()
         gpu_s, wall_s = gpu_ms.value * 1e-3, t1 - t0
-        if lanes:
-            # the K steps' own bracket: ga3c_net_time_predict_lanes reads the host clock from the moment every lane may start
-            # (the device synchronised, each lane's copy of the resident batch in place) to the moment every lane's last step
-            # has been waited for; the Python-level clock around the call also holds that input staging (a device-to-device
-            # copy of the batch per lane) and is kept as `outer`
-            wall_s, outer_s = ev_ms.value * 1e-3, t1 - t0
-        else:
-            outer_s = wall_s
+        # (the lanes' copies of the resident batch are made once per uploaded batch, by the warm-up call: nothing but the K
+        # steps sits between the two synchronisations.  ga3c_net_time_predict_lanes also reads the host clock itself, from
+        # the release of the lanes to the last lane's wait: the `inner` figure, a few microseconds of call overhead shorter)
+        inner_s = ev_ms.value * 1e-3 if lanes else wall_s
         if world > 1:
             rv.barrier()
-            gpu_s, wall_s, outer_s = rv.reduce([gpu_s, wall_s, outer_s])
-        outer_walls.append(outer_s)
+            gpu_s, wall_s, inner_s = rv.reduce([gpu_s, wall_s, inner_s])
+        inner_walls.append(inner_s)
         return gpu_s, wall_s
 
     MIN_TIMED_S, MAX_BLOCKS = 0.05, 400
     blocks_used = {}
-    outer_walls = []
+    inner_walls = []
 
     def timed(mode, steps, lanes=0, tag=None, rows=None):
         """A K-step block of this path lasts well under a millisecond at the driver's K = 20: the bracketed K-step block is
@@ -282,9 +278,9 @@ def main():
         net.close()
         print(json.dumps(dict(res, hardware_queues=os.environ.get("GPU_MAX_HW_QUEUES"))))
         return
-    del outer_walls[:]
+    del inner_walls[:]
     pred_gpu_s, pred_s = timed(0, K, lanes=NP, tag="predict")      # pred_s: host wall-clock of the median bracketed block
-    pred_outer_s = float(np.median(outer_walls))
+    pred_inner_s = float(np.median(inner_walls))
     one_s = timed(0, K, lanes=1)[1]
     sweep = {}
     if not args.no_lane_sweep:
@@ -355,15 +351,15 @@ def main():
                                        "beyond three share the three prediction streams (ga3c_net_create: the engine keeps to "
                                        "four normal-priority streams)" % NP),
             "gpu_span_ms_per_step": pred_gpu_s / K * 1e3, "value_gpu_span": world * K * B / pred_gpu_s,
-            "outer_wall_ms_per_step": pred_outer_s / K * 1e3,
-            "timing": "ms_per_step / value: HOST WALL-CLOCK of the median bracketed K-step block, max over ranks: behind the "
-                      "barrier and a device synchronisation, from the moment the lanes may start to the moment every lane's last "
-                      "step has been waited for (read inside ga3c_net_time_predict_lanes; launch latency of the first kernel and "
-                      "the wake-up of the waiting host threads are in it).  gpu_span_ms_per_step / value_gpu_span: HIP events on "
-                      "the lanes' streams, first start to last end (round 3's headline).  outer_wall_ms_per_step: the Python-level "
-                      "clock around the same call, which also holds the staging of the resident batch into each lane's workspace "
-                      "(a device-to-device copy per lane before the lanes start) -- inputs resident when the timed region starts "
-                      "is this bench's contract, so that copy is not part of a step",
+            "inner_wall_ms_per_step": pred_inner_s / K * 1e3,
+            "timing": "ms_per_step / value: HOST WALL-CLOCK (time.perf_counter) of the median bracketed K-step block, max over "
+                      "ranks: barrier + device synchronisation, the K steps, device synchronisation -- rounds 1 and 2's "
+                      "definition; launch latency of the first kernel, the wake-up of the lanes' host threads and of the "
+                      "waiting caller are in it.  Each lane's copy of the resident batch is made once per uploaded batch (by "
+                      "the warm-up call), not inside the bracket (until round 4 it was re-made by every timed call: +2 us per "
+                      "step at K = 20).  gpu_span_ms_per_step / value_gpu_span: HIP events on the lanes' streams, first start to "
+                      "last end (round 3's headline).  inner_wall_ms_per_step: the host clock read inside "
+                      "ga3c_net_time_predict_lanes, from the release of the lanes to the last lane's wait",
             "cpu_placement": placement, "torch_imported": "torch" in sys.modules,
             "train": {"metric": "training_steps_per_sec", "value": tps, "unit": "steps/s",
                       "ms_per_step": train_s / K * 1e3 if train_s else None, "rows_per_step": world * B,
