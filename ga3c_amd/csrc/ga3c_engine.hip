@@ -1327,7 +1327,8 @@ void free_train_lane(TrainLane& t) {
 }
 
 int sync_all(ga3c_net* net) {
-  for (Lane* L : net->lanes) HIPCHK(hipStreamSynchronize(L->st));
+  for (size_t i = 0; i < net->lanes.size(); ++i)             // (lanes beyond the lane streams borrow one: each stream once)
+    if (net->lanes[i]->owns_st) HIPCHK(hipStreamSynchronize(net->lanes[i]->st));
   HIPCHK(hipStreamSynchronize(net->tr.st));
   for (TrainLane* t : net->xtr) HIPCHK(hipStreamSynchronize(t->st));
   {
