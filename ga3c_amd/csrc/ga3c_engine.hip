@@ -318,6 +318,7 @@ struct ga3c_net {
   // still being computed on the train stream; the 49 KB in front follow when they are done
   hipStream_t cst = nullptr;
   hipEvent_t ev_tail_ready = nullptr, ev_head_ready = nullptr, ev_comm_done = nullptr;
+  bool head_on_train_stream = true;    // GA3C_COMM_HEAD_INLINE=0: the conv gradients' exchange hops to the comm stream too (round 3)
   bool comm_overlap = true;            // GA3C_COMM_OVERLAP=0: one blocking all-reduce of the whole arena behind the backward pass
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
@@ -534,6 +535,7 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     HIPCHK(hipEventRecord(net->ev_tail_ready, st));
     HIPCHK(hipStreamWaitEvent(net->cst, net->ev_tail_ready, 0));
     NCCLCHK(ncclAllReduce(g + OFF_WD, g + OFF_WD, (size_t)(net->n - OFF_WD), ncclFloat, ncclSum, net->comm, net->cst));
+    if (net->head_on_train_stream) HIPCHK(hipEventRecord(net->ev_comm_done, net->cst));   // (waited for below, behind the head's exchange)
   }
   int nch1, nch2;
   if (fused_cb) {   // one workgroup per CU: beyond one round the tail of the second costs more than the fusion saves
@@ -570,7 +572,15 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     else hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(s1.nblocks + s2.nblocks), dim3(1024), 0, st, s1, s2, upd);
   }
   HIPCHK(hipGetLastError());
-  if (overlap) {
+  if (overlap && net->head_on_train_stream) {
+    // The conv gradients (12 k floats) are complete only now, with nothing left to overlap their exchange with: it goes on the
+    // TRAIN stream itself, in line, instead of a hop to the comm stream and back (two cross-queue dependencies, ~7 us each on
+    // the GPU, and two more API calls on a host that is the bottleneck of this path: profiles/r04_dp_1rank_timeline.txt).
+    // RCCL runs the collectives of one communicator in the order they were issued -- identical on every rank --, so this one
+    // starts behind the big one on the comm stream; the optimizer step then waits for both.
+    NCCLCHK(ncclAllReduce(g, g, (size_t)OFF_WD, ncclFloat, ncclSum, net->comm, st));
+    HIPCHK(hipStreamWaitEvent(st, net->ev_comm_done, 0));
+  } else if (overlap) {
     HIPCHK(hipEventRecord(net->ev_head_ready, st));
     HIPCHK(hipStreamWaitEvent(net->cst, net->ev_head_ready, 0));
     NCCLCHK(ncclAllReduce(g, g, (size_t)OFF_WD, ncclFloat, ncclSum, net->comm, net->cst));
@@ -2805,6 +2815,7 @@ int ga3c_net_comm_init(ga3c_net* net, const uint8_t id[GA3C_COMM_ID_BYTES], int3
   net->world = world;
   net->rank = rank;
   net->comm_overlap = !(getenv("GA3C_COMM_OVERLAP") && atoi(getenv("GA3C_COMM_OVERLAP")) == 0);
+  net->head_on_train_stream = !(getenv("GA3C_COMM_HEAD_INLINE") && atoi(getenv("GA3C_COMM_HEAD_INLINE")) == 0);
   HIPCHK(stream_take(net->cfg.device, false, &net->cst));
   for (hipEvent_t* e : {&net->ev_tail_ready, &net->ev_head_ready, &net->ev_comm_done})
     HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
