@@ -2413,10 +2413,22 @@ static int stage_history_rows(ga3c_net* net, Stage& s, const int32_t* agents, co
   const int64_t total = (int64_t)batch * (IMG * IMG / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 512) blocks = 512;      // (reads HBM, not the bus: two workgroups per CU leave the other wave slots to a step in flight)
-  hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, s.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, s.xu8, batch);
+  // returns and actions ride in the same launch (staged behind the x region of h_in: the ids at its start stay untouched)
+  float* hy = s.h_in + (size_t)net->maxB * XS;
+  float* ha = hy + net->maxB;
+  SmallCopy sc{nullptr, nullptr, 0, nullptr, nullptr, 0};
+  if (y_r) { memcpy(hy, y_r, (size_t)batch * sizeof(float)); sc.src0 = hy; sc.dst0 = s.yr; sc.n0 = batch; }
+  if (a) { memcpy(ha, a, (size_t)batch * net->A * sizeof(float)); sc.src1 = ha; sc.dst1 = s.act; sc.n1 = batch * net->A; }
+  HistRows hr;
+  hr.n = 0;
+  if (batch <= 192) {
+    for (int i = 0; i < batch; ++i) { hr.seq[i] = seqs[i]; hr.agent[i] = agents[i]; }
+    hr.n = batch;
+  }
+  hipLaunchKernelGGL(gather_history_kernel, dim3(blocks), dim3(256), 0, s.st, f.ring, h_ag, h_seq, f.hist, IMG * IMG, s.xu8, batch, sc, hr);
   HIPCHK(hipGetLastError());
-  s.x_u8 = true;   // (y_r and a are staged behind the x region of h_in: the ids at its start stay untouched)
-  return stage_train_inputs(net, s, nullptr, false, y_r, a, batch);
+  s.x_u8 = true;
+  return GA3C_OK;
 }
 
 int ga3c_net_frames_upload(ga3c_net* net, const uint8_t* rgb, int32_t n) {

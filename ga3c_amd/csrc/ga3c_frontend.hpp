@@ -249,34 +249,64 @@ __global__ __launch_bounds__(256) void plane_push_kernel(FrameArgs a) {
   uint32_t* stack = agent >= 0 ? a.stacks + (size_t)agent * nout : nullptr;
   uint8_t* plane = a.planes ? a.planes + (size_t)f * nout : nullptr;
   uint8_t* hist = (a.ring && agent >= 0) ? a.ring + ((size_t)agent * a.hist + a.ring_slot[f]) * nout : nullptr;
-  for (int p0 = 4 * threadIdx.x; p0 < nout; p0 += 4 * 256) {       // nout % 4 == 0 (checked on the host)
-    uint4 s = make_uint4(0, 0, 0, 0);
-    if (stack && !clear) s = *reinterpret_cast<const uint4*>(stack + p0);
-    const uint32_t px4 = *reinterpret_cast<const uint32_t*>(src + p0);
-    if (plane) *reinterpret_cast<uint32_t*>(plane + p0) = px4;
-    if (hist) *reinterpret_cast<uint32_t*>(hist + p0) = px4;
-    if (stack) {
-      s.x = (s.x >> 8) | ((px4 & 255u) << 24);
-      s.y = (s.y >> 8) | (((px4 >> 8) & 255u) << 24);
-      s.z = (s.z >> 8) | (((px4 >> 16) & 255u) << 24);
-      s.w = (s.w >> 8) | ((px4 >> 24) << 24);
-      *reinterpret_cast<uint4*>(stack + p0) = s;
+  // The plane lies in the transport's registered host segment: every load of it is a trip over PCIe.  All of a thread's loads
+  // are requested before the first is used -- as one load per trip of the loop (round 3) the kernel paid seven bus round
+  // trips in a row, 26.7 us per batch of 80 planes and the biggest kernel of the running engine (30 % of the GPU's time with
+  // 256 agents, profiles/README.md, round 4) for 565 KB that the bus moves in 16 us.
+  constexpr int TRIPS = 8;                                          // 8 x 1024 pixels >= 84 x 84
+  for (int q0 = 0; q0 < nout; q0 += 4 * 256 * TRIPS) {
+    uint32_t px[TRIPS];
+    uint4 st[TRIPS];
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int p0 = q0 + 4 * (256 * k + (int)threadIdx.x);        // nout % 4 == 0 (checked on the host)
+      px[k] = p0 < nout ? *reinterpret_cast<const uint32_t*>(src + p0) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int p0 = q0 + 4 * (256 * k + (int)threadIdx.x);
+      st[k] = (stack && !clear && p0 < nout) ? *reinterpret_cast<const uint4*>(stack + p0) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < TRIPS; ++k) {
+      const int p0 = q0 + 4 * (256 * k + (int)threadIdx.x);
+      if (p0 >= nout) continue;
+      const uint32_t px4 = px[k];
+      if (plane) *reinterpret_cast<uint32_t*>(plane + p0) = px4;
+      if (hist) *reinterpret_cast<uint32_t*>(hist + p0) = px4;
+      if (stack) {
+        uint4 s = st[k];
+        s.x = (s.x >> 8) | ((px4 & 255u) << 24);
+        s.y = (s.y >> 8) | (((px4 >> 8) & 255u) << 24);
+        s.z = (s.z >> 8) | (((px4 >> 16) & 255u) << 24);
+        s.w = (s.w >> 8) | ((px4 >> 24) << 24);
+        *reinterpret_cast<uint4*>(stack + p0) = s;
+      }
     }
   }
 }
 
 // Training rows out of the plane history: x[b] = the [OH,OW,4] uint8 state whose newest plane is history entry
 // seq[b] of agent[b] (planes seq-3 .. seq, oldest first) -- what the agent's queue held right after that push.
+// The rows' names travel with the launch (n > 0) instead of being read out of the pinned arrays -- every work item's loads
+// waited for two scalar loads over PCIe in front of them -- and the batch's returns and actions ride along (SmallCopy: the last
+// workgroup copies them out of pinned memory; as two hipMemcpyAsync they were two 5-us copy kernels on the train stream in
+// front of every step: 7 % of the GPU's time in the running engine, profiles/README.md, round 4).
+struct HistRows { int64_t seq[192]; int32_t agent[192]; int n; };
+
 __global__ __launch_bounds__(256) void gather_history_kernel(const uint8_t* __restrict__ ring, const int32_t* __restrict__ agents,
                                                              const int64_t* __restrict__ seqs, int hist, int nout,
-                                                             uint8_t* __restrict__ x, int B) {
+                                                             uint8_t* __restrict__ x, int B, SmallCopy sc, const HistRows hr) {
+  if (blockIdx.x == gridDim.x - 1) small_copy(sc);
   const int groups = nout / 4;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)B * groups; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / groups), g = (int)(i - (int64_t)b * groups);
-    const uint8_t* base = ring + (size_t)agents[b] * hist * nout;
+    const int ag = hr.n ? hr.agent[b < 192 ? b : 0] : agents[b];
+    const int64_t sq = hr.n ? hr.seq[b < 192 ? b : 0] : seqs[b];
+    const uint8_t* base = ring + (size_t)ag * hist * nout;
     uint32_t w[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) w[c] = *reinterpret_cast<const uint32_t*>(base + (size_t)((seqs[b] - 3 + c) % hist) * nout + 4 * g);
+    for (int c = 0; c < 4; ++c) w[c] = *reinterpret_cast<const uint32_t*>(base + (size_t)((sq - 3 + c) % hist) * nout + 4 * g);
     uint4 o;   // pixel q of the group: bytes (plane0, plane1, plane2, plane3)
     o.x = (w[0] & 255u) | ((w[1] & 255u) << 8) | ((w[2] & 255u) << 16) | ((w[3] & 255u) << 24);
     o.y = ((w[0] >> 8) & 255u) | (((w[1] >> 8) & 255u) << 8) | (((w[2] >> 8) & 255u) << 16) | (((w[3] >> 8) & 255u) << 24);
