@@ -140,7 +140,9 @@ def test_credit_protocol_under_fast_steps_and_a_late_rank(tmp_path):
             if rank == 1:
                 time.sleep(float(rng.uniform(0.0, 0.12)))      # up to a dozen poll periods late
             lr = 1e-3 * (1 + steps[0] // 500)                   # rank 0's schedule moves while steps are in flight
-            g.poll(time.time() - t0 > 1.5, steps[rank], lr if rank == 0 else 99.0, 0.01)
+            # (a rank asks to stop once it has seen 1,200 steps -- a count, not a time: a loaded machine only makes the test
+            # longer -- or after 30 s, so that a protocol failure ends in the asserts below rather than in a hang)
+            g.poll(steps[rank] >= 1200 or time.time() - t0 > 30, steps[rank], lr if rank == 0 else 99.0, 0.01)
             time.sleep(0.01)
         done[rank] = True
 
@@ -164,7 +166,7 @@ def test_a_rank_that_never_joins_a_step_is_named_and_the_group_stops(tmp_path, m
     import time
     import ga3c_amd  # noqa: F401
     import DataParallel as dp
-    monkeypatch.setenv("GA3C_DP_STALL_S", "0.5")
+    monkeypatch.setenv("GA3C_DP_STALL_S", "1.0")
     world, port = 3, 46000 + os.getpid() % 10000
     groups = [None] * world
 
@@ -176,7 +178,7 @@ def test_a_rank_that_never_joins_a_step_is_named_and_the_group_stops(tmp_path, m
         t.start()
     for t in ths:
         t.join(30)
-    assert all(groups) and groups[0].STALL_S == 0.5
+    assert all(groups) and groups[0].STALL_S == 1.0
     steps, raised = [0] * world, [None] * world
     collective = threading.Barrier(world)
     halt = threading.Event()
@@ -222,7 +224,7 @@ def test_a_rank_that_never_joins_a_step_is_named_and_the_group_stops(tmp_path, m
     assert all(raised), raised
     assert "rank 1 " in raised[0] and "train step 21" in raised[0]
     assert "rank 1 " in raised[1] and "rank 1 " in raised[2]          # every rank names the same late rank
-    assert steps == [20, 20, 20] and took < 10
+    assert steps == [20, 20, 20] and took < 15
 
 
 def test_rendezvous_reduce_is_the_max_and_the_sum_over_the_ranks(tmp_path):
