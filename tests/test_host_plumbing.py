@@ -859,19 +859,19 @@ def test_pop_batch_linger_collects_stragglers_only_when_asked(mods):
         t.respond(np.array([0, 1, 2], np.uint32), 3, np.zeros((3, 6), np.float32), np.zeros(3, np.float32))
         for a in range(3):
             assert t.wait(a, 1000)[0] == 0
-        t.set_linger(300000, 3)                                              # up to 0.3 s for a batch of 3
+        t.set_linger(1000000, 3)                                             # up to 1 s for a batch of 3 (wide: loaded machines)
         t.submit(0)
         th = threading.Thread(target=late, args=([1, 2], 0.02))
         th.start()
         t0 = time.time()
-        assert t.pop_batch(ids, 1000) == 3 and sorted(ids[:3].tolist()) == [0, 1, 2]
-        assert time.time() - t0 < 0.25                                       # left as soon as the batch was there
+        assert t.pop_batch(ids, 3000) == 3 and sorted(ids[:3].tolist()) == [0, 1, 2]
+        assert time.time() - t0 < 0.9                                        # left as soon as the batch was there
         th.join()
         t.respond(np.array([0, 1, 2], np.uint32), 3, np.zeros((3, 6), np.float32), np.zeros(3, np.float32))
         t.submit(4)
         t0 = time.time()
-        assert t.pop_batch(ids, 1000) == 1                                   # nobody else comes: gives up after linger_us
-        assert 0.25 < time.time() - t0 < 0.6
+        assert t.pop_batch(ids, 3000) == 1                                   # nobody else comes: gives up after linger_us
+        assert 0.9 < time.time() - t0 < 2.5
     finally:
         t.shutdown()
         t.close()
