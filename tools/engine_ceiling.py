@@ -96,7 +96,8 @@ def main():
                 "eng": srv.model.stats() if hasattr(srv.model, "stats") else {},
                 "batches": sum(p.batches for p in srv.predictors),
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")},
-                "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive())}
+                "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive()),
+                "rss_mb": next((int(l.split()[1]) / 1024 for l in open("/proc/self/status") if l.startswith("VmRSS")), 0)}
 
     out = {}
 
@@ -147,7 +148,8 @@ def main():
         "predictions_per_sec": round(pred / dt), "train_steps_per_sec": round((b["steps"] - a["steps"]) / dt, 1),
         "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),
         "predictor_us_per_batch": {k: round((b["loop"][k] - a["loop"][k]) / batches * 1e6, 1) for k in b["loop"]},
-        "pcie_gb_per_s_states": round(pred / dt * state_bytes / 1e9, 2), "threads_died": b["died"], "tool": out.get("tool")}))
+        "pcie_gb_per_s_states": round(pred / dt * state_bytes / 1e9, 2), "threads_died": b["died"],
+        "server_rss_mb_start_end": [round(a["rss_mb"]), round(b["rss_mb"])], "tool": out.get("tool")}))
 
 
 if __name__ == "__main__":
