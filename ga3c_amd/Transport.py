@@ -165,6 +165,13 @@ class Transport:
     def set_spin(self, spin_us):
         nat.check_host(self._lib.ga3c_pq_set_spin(self._h, int(spin_us)), "ga3c_pq_set_spin")
 
+    def wake_latency(self):
+        """{'ready': (answers, mean us, max us), 'slept': (...)}: answer published -> agent back from its wait (ga3c_pq_wake_latency)."""
+        out = np.zeros(6, np.int64)
+        nat.check_host(self._lib.ga3c_pq_wake_latency(self._h, out.ctypes.data), "ga3c_pq_wake_latency")
+        return {k: (int(out[3 * i]), float(out[3 * i + 1]) / max(int(out[3 * i]), 1) / 1e3, float(out[3 * i + 2]) / 1e3)
+                for i, k in enumerate(("ready", "slept"))}
+
     def set_linger(self, linger_us, min_batch):
         nat.check_host(self._lib.ga3c_pq_set_linger(self._h, int(linger_us), int(min_batch)), "ga3c_pq_set_linger")
 

@@ -192,7 +192,13 @@ struct AgentMeta {   // lives right behind each agent's state bytes
   uint32_t req_flags;                // written by the agent before it submits (GA3C_REQ_*), read by the predictor
   uint32_t req_epoch;                // times req_seq has wrapped (written by the agent only): request number = epoch << 32 | seq
   std::atomic<uint32_t> waiting;     // 1 while the agent is (about to be) asleep on resp_seq: only then does an answer cost a syscall
-  uint32_t pad[58];
+  uint32_t pad0;
+  // answer -> agent running again (ga3c_pq_wake_latency): stamped by the predictor, summed by the agent; CLOCK_MONOTONIC, ns
+  uint64_t answered_ns;              // when ga3c_pq_respond published the newest answer
+  uint64_t lat_sum_ns[2];            // [0] the answer was there or came while polling, [1] the agent had gone to sleep on the futex
+  uint32_t lat_count[2];
+  uint32_t lat_max_ns[2];
+  uint32_t pad[46];
 };
 static_assert(sizeof(AgentMeta) == 512, "AgentMeta must stay 512 bytes");
 
@@ -749,6 +755,7 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
   // An answer that is already there, or arrives within spin_us, costs neither side a system call: the agent announces its
   // sleep in `waiting` (then looks once more), ga3c_pq_respond publishes the answer and wakes only an agent that has announced
   // it.  Both sides use sequentially consistent accesses, so one of them always sees the other's store.
+  int slept = 0;
   const int32_t spin_us = h->spin_us.load(std::memory_order_relaxed);
   if (spin_us > 0 && m->resp_seq.load(std::memory_order_acquire) != want) {
     const int64_t until = now_ns() + (int64_t)spin_us * 1000;
@@ -766,11 +773,34 @@ int ga3c_pq_wait(ga3c_shm* shm, int32_t agent, float* p, float* v, int32_t timeo
     }
     m->waiting.store(1, std::memory_order_seq_cst);
     got = m->resp_seq.load(std::memory_order_seq_cst);
-    if (got != want) futex_wait(&m->resp_seq, got, wait_ms);
+    if (got != want) { futex_wait(&m->resp_seq, got, wait_ms); slept = 1; }
     m->waiting.store(0, std::memory_order_relaxed);
+  }
+  {
+    const int64_t age = now_ns() - (int64_t)m->answered_ns;      // both sides read CLOCK_MONOTONIC: comparable across processes
+    if (age >= 0 && age < (int64_t)4000000000) {
+      m->lat_sum_ns[slept] += (uint64_t)age;
+      m->lat_count[slept] += 1;
+      if ((uint32_t)age > m->lat_max_ns[slept]) m->lat_max_ns[slept] = (uint32_t)age;
+    }
   }
   memcpy(p, m->p, (size_t)h->cfg.num_actions * sizeof(float));
   *v = m->v;
+  return GA3C_H_OK;
+}
+
+int ga3c_pq_wake_latency(ga3c_shm* shm, int64_t* out6) {
+  if (!shm || !out6) return fail(GA3C_H_EINVAL, "bad argument");
+  int64_t r[6] = {0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < shm->hdr()->cfg.max_agents; ++a) {
+    const AgentMeta* m = shm->meta(a);
+    for (int k = 0; k < 2; ++k) {
+      r[3 * k + 0] += m->lat_count[k];
+      r[3 * k + 1] += (int64_t)m->lat_sum_ns[k];
+      if ((int64_t)m->lat_max_ns[k] > r[3 * k + 2]) r[3 * k + 2] = m->lat_max_ns[k];
+    }
+  }
+  memcpy(out6, r, sizeof r);
   return GA3C_H_OK;
 }
 
@@ -865,6 +895,7 @@ int ga3c_pq_respond(ga3c_shm* shm, const uint32_t* ids, int32_t n, const float* 
     AgentMeta* m = shm->meta((int)ids[i]);
     memcpy(m->p, p + (size_t)i * A, (size_t)A * sizeof(float));
     m->v = v[i];
+    m->answered_ns = (uint64_t)now_ns();
     m->resp_seq.store(m->req_seq, std::memory_order_seq_cst);
     if (m->waiting.load(std::memory_order_seq_cst) != 0) futex_wake(&m->resp_seq, 1);
   }

@@ -110,6 +110,13 @@ int ga3c_pq_round_trip(ga3c_shm* shm, int32_t agent, const void* state, int32_t 
  * agent is still awake costs neither side a system call: ga3c_pq_respond wakes only agents that have announced their sleep.
  * (wait_q.get() of ProcessAgent.py:105-106 blocks in a pipe read; this is the futex counterpart.) */
 int ga3c_pq_set_spin(ga3c_shm* shm, int32_t spin_us);
+/* What a wake costs on this machine: time from ga3c_pq_respond publishing an agent's answer to that agent returning from
+ * ga3c_pq_wait, summed over all agents since the segment was created (each agent adds its own; read them when the agents are
+ * quiet or take differences).  out6 = {answers, sum ns, max ns} of answers that were there already or came while the agent
+ * polled, then the same three for answers the agent had gone to sleep for (FUTEX_WAIT): the second group's mean is the
+ * scheduler's wake-to-run latency, which bounds an engine with many light agents.  No counterpart in
+ * the reference (its wait is multiprocessing.Queue.get, ProcessAgent.py:98). */
+int ga3c_pq_wake_latency(ga3c_shm* shm, int64_t* out6);
 /* Environment._update_frame_q + _get_current_state (Environment.py:62-74) for the 4-deep frame queue kept as one
  * little-endian uint32 per pixel (byte c = frame c, oldest first): out[i] = (in[i] >> 8) | (plane[i] << 24), i < n.  The
  * words of `out` are the [84,84,4] uint8 state with the new plane as its newest frame; `in` is left untouched (experiences

@@ -442,6 +442,11 @@ def test_an_answer_that_is_already_there_costs_no_wake_and_a_spinning_agent_sees
             rc, p, v = got["r"]
             assert rc == 0 and v == 1.25 and p.tolist() == [0.5] * 6
             assert t.agent_idle(2)
+        # ga3c_pq_wake_latency: the four answers above, by whether the agent had gone to sleep for them -- the one that was
+        # there already and the one that came while the agent polled on one side, the two sleepers on the other
+        lat = t.wake_latency()
+        assert lat["ready"][0] == 2 and lat["slept"][0] == 2
+        assert 0 < lat["slept"][1] < 1e6 and lat["slept"][2] >= lat["slept"][1] and lat["ready"][1] > 0
     finally:
         t.shutdown()
         t.close()

@@ -94,7 +94,8 @@ def main():
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")}, "srv_cpu": cpu_of([me]), "agent_cpu": cpu_of(kids),
                 "cg": cgroup(), "eng": srv.model.stats() if hasattr(srv.model, "stats") else {},
                 "n_kids": len(kids), "n_agents": len(srv.agents), "alive": sum(1 for a in srv.agents if a.is_alive()), "n_pred": len(srv.predictors), "n_train": len(srv.trainers),
-                "rss_mb": round(me.memory_info().rss / 2 ** 20), "spills": sum(t.spills for t in srv.trainers), "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive())}
+                "rss_mb": round(me.memory_info().rss / 2 ** 20), "spills": sum(t.spills for t in srv.trainers), "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive()),
+                "wake": srv.transport.wake_latency()}
 
     def sampler():
         time.sleep(args.warm)
@@ -134,7 +135,11 @@ def main():
         "agent_cpu_us_per_step": round((b["agent_cpu"] - a["agent_cpu"]) / max(1, pred) * 1e6, 1),
         "agent_wall_us_per_step": round(dt * args.agents / max(1, pred) * 1e6, 1),
         "workers_at_end": {"agents": b["n_agents"], "agents_alive": b["alive"], "predictors": b["n_pred"], "trainers": b["n_train"]},
-        "server_rss_mb_start_end": [a["rss_mb"], b["rss_mb"]], "threads_died": b["died"], "trainer_spills": sum(t.spills for t in srv.trainers) if srv.trainers else b["spills"]}))
+        "server_rss_mb_start_end": [a["rss_mb"], b["rss_mb"]], "threads_died": b["died"],
+        "answer_to_running_us": {k: {"answers": b["wake"][k][0] - a["wake"][k][0],
+                                      "mean": round((b["wake"][k][1] * b["wake"][k][0] - a["wake"][k][1] * a["wake"][k][0]) / max(b["wake"][k][0] - a["wake"][k][0], 1), 1),
+                                      "max_since_start": round(b["wake"][k][2], 1)} for k in ("ready", "slept")},
+        "trainer_spills": sum(t.spills for t in srv.trainers) if srv.trainers else b["spills"]}))
 
 
 if __name__ == "__main__":

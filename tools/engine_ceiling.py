@@ -96,7 +96,7 @@ def main():
                 "eng": srv.model.stats() if hasattr(srv.model, "stats") else {},
                 "batches": sum(p.batches for p in srv.predictors),
                 "loop": {k: sum(p.seconds[k] for p in srv.predictors) for k in ("pop", "predict", "respond")},
-                "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive()),
+                "died": sum(1 for t in srv.predictors + srv.trainers if not t.is_alive()), "wake": srv.transport.wake_latency(),
                 "rss_mb": next((int(l.split()[1]) / 1024 for l in open("/proc/self/status") if l.startswith("VmRSS")), 0)}
 
     out = {}
@@ -149,6 +149,9 @@ def main():
         "mean_predict_batch": round(pred / batches, 1), "predict_batches_per_sec": round(batches / dt),
         "predictor_us_per_batch": {k: round((b["loop"][k] - a["loop"][k]) / batches * 1e6, 1) for k in b["loop"]},
         "pcie_gb_per_s_states": round(pred / dt * state_bytes / 1e9, 2), "threads_died": b["died"],
+        "answer_to_running_us": {k: {"answers": b["wake"][k][0] - a["wake"][k][0],
+                                      "mean": round((b["wake"][k][1] * b["wake"][k][0] - a["wake"][k][1] * a["wake"][k][0]) / max(b["wake"][k][0] - a["wake"][k][0], 1), 1),
+                                      "max_since_start": round(b["wake"][k][2], 1)} for k in ("ready", "slept")},
         "server_rss_mb_start_end": [round(a["rss_mb"]), round(b["rss_mb"])], "tool": out.get("tool")}))
 
 

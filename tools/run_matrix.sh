@@ -15,7 +15,7 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[2]).read())
     keys = ('predictions_per_sec', 'train_steps_per_sec', 'training_steps_per_sec', 'mean_predict_batch', 'predictor_us_per_batch',
-            'us_cpu_per_prediction', 'cgroup')
+            'us_cpu_per_prediction', 'answer_to_running_us', 'cgroup')
     pl = d.get('placement') or {}
     print(sys.argv[1], {k: d[k] for k in keys if k in d}, 'cpus', len(pl.get('cpus', [])) or 'unplaced', flush=True)
 except Exception as e:
