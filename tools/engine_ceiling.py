@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--train-min-batch", type=int, default=127)
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--linger-us", type=int, default=0)
+    ap.add_argument("--linger-batch", type=int, default=0)
     ap.add_argument("--hogwild", action="store_true")
     ap.add_argument("--frame-queue-on-device", action="store_true",
                     help="FRAME_SOURCE = 'planes', FRONTEND = 'device': agents ship their newest plane, states stay in HBM")
@@ -51,6 +53,7 @@ def main():
     Config.AGENTS, Config.PREDICTORS, Config.TRAINERS = 0, args.predictors, args.trainers
     Config.DYNAMIC_SETTINGS = False
     Config.PREDICTION_BATCH_SIZE = args.batch
+    Config.PREDICTION_LINGER_US, Config.PREDICTION_LINGER_BATCH = args.linger_us, args.linger_batch
     Config.TRAINING_MIN_BATCH_SIZE = args.train_min_batch
     Config.TRAIN_MODELS = not args.no_train
     Config.HOGWILD = bool(args.hogwild)
