@@ -228,11 +228,12 @@ def main():
         t0 = time.perf_counter()
         if lanes:
             nat.check(lib.ga3c_net_time_predict_lanes(h, rows, steps, lanes, nat.C.byref(ev_ms)), "time_predict_lanes")
-            nat.check(lib.ga3c_net_last_lanes_gpu_ms(h, nat.C.byref(gpu_ms)), "last_lanes_gpu_ms")
         else:
             nat.check(lib.ga3c_net_time_resident(h, mode, rows, steps, lr, beta, nat.C.byref(gpu_ms)), "time_resident")
         device_sync()
         t1 = time.perf_counter()
+        if lanes:                                          # (the events' arithmetic: after the clock has been read)
+            nat.check(lib.ga3c_net_last_lanes_gpu_ms(h, nat.C.byref(gpu_ms)), "last_lanes_gpu_ms")
         gpu_s, wall_s = gpu_ms.value * 1e-3, t1 - t0
         # (the lanes' copies of the resident batch are made once per uploaded batch, by the warm-up call: nothing but the K
         # steps sits between the two synchronisations.  ga3c_net_time_predict_lanes also reads the host clock itself, from

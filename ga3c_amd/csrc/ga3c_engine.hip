@@ -357,6 +357,7 @@ struct ga3c_net {
   TensorTable tt;
   LaneDrivers drv;
   float lanes_gpu_ms = 0.f;            // GPU-side span of the last ga3c_net_time_predict_lanes block (first start event .. last end event)
+  int lanes_gpu_n = 0;
   int gather_max_blocks = 32;          // workgroups of the PCIe gather (GA3C_GATHER_BLOCKS; ga3c_kernels.hpp: gather_rows_kernel)
   int lane_streams = 3;                // HIP streams the prediction lanes are spread over (GA3C_LANE_STREAMS)
   std::atomic<uint64_t> resident_gen{1};   // moves whenever the train lane's resident batch is (re)written
@@ -2603,20 +2604,25 @@ int ga3c_net_time_predict_lanes(ga3c_net* net, int32_t batch, int32_t iters, int
   *elapsed_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
   for (int l = 0; l < nlanes; ++l)
     if (d.rcs[l] != GA3C_OK) return fail(d.rcs[l], "prediction lane %d failed: %s", l, d.errs[l].c_str());
-  // the block as the GPU saw it: from the earliest lane's start event to the latest lane's end event
-  float span = 0.f;
-  for (int i = 0; i < nlanes; ++i)
-    for (int j = 0; j < nlanes; ++j) {
-      float ms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, net->lanes[i]->tm0, net->lanes[j]->tm1));
-      if (ms > span) span = ms;
-    }
-  net->lanes_gpu_ms = span;
+  net->lanes_gpu_ms = -1.f;                                  // worked out by ga3c_net_last_lanes_gpu_ms, outside the caller's clock
+  net->lanes_gpu_n = nlanes;
   return GA3C_OK;
 }
 
 int ga3c_net_last_lanes_gpu_ms(ga3c_net* net, float* gpu_ms) {
   if (!net || !gpu_ms) return fail(GA3C_EINVAL, "null argument");
+  if (net->lanes_gpu_ms < 0.f) {
+    // the block as the GPU saw it: from the earliest lane's start event to the latest lane's end event
+    HIPCHK(hipSetDevice(net->cfg.device));
+    float span = 0.f;
+    for (int i = 0; i < net->lanes_gpu_n; ++i)
+      for (int j = 0; j < net->lanes_gpu_n; ++j) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, net->lanes[i]->tm0, net->lanes[j]->tm1));
+        if (ms > span) span = ms;
+      }
+    net->lanes_gpu_ms = span;
+  }
   *gpu_ms = net->lanes_gpu_ms;
   return GA3C_OK;
 }
