@@ -1337,11 +1337,20 @@ void free_train_lane(TrainLane& t) {
   if (t.st) stream_give_back(t.st);
 }
 
+// (a stream with nothing pending answers hipStreamQuery at once; hipStreamSynchronize on it costs several microseconds
+// all the same -- five idle streams were 30 us of a bracketed 20-step block)
+static hipError_t sync_stream(hipStream_t st) {
+  const hipError_t q = hipStreamQuery(st);
+  if (q == hipSuccess) return hipSuccess;
+  if (q != hipErrorNotReady) return q;
+  return hipStreamSynchronize(st);
+}
+
 int sync_all(ga3c_net* net) {
   for (size_t i = 0; i < net->lanes.size(); ++i)             // (lanes beyond the lane streams borrow one: each stream once)
-    if (net->lanes[i]->owns_st) HIPCHK(hipStreamSynchronize(net->lanes[i]->st));
-  HIPCHK(hipStreamSynchronize(net->tr.st));
-  for (TrainLane* t : net->xtr) HIPCHK(hipStreamSynchronize(t->st));
+    if (net->lanes[i]->owns_st) HIPCHK(sync_stream(net->lanes[i]->st));
+  HIPCHK(sync_stream(net->tr.st));
+  for (TrainLane* t : net->xtr) HIPCHK(sync_stream(t->st));
   {
     std::lock_guard<std::mutex> g(net->ready_mu);   // nothing is in flight: the newest weights are complete
     net->cur.store(net->latest);   // (event_valid is irrelevant while cur == latest)
