@@ -1343,6 +1343,7 @@ static hipError_t sync_stream(hipStream_t st) {
   const hipError_t q = hipStreamQuery(st);
   if (q == hipSuccess) return hipSuccess;
   if (q != hipErrorNotReady) return q;
+  (void)hipGetLastError();                           // "not ready" is an answer, not a failure: it must not surface in a later hipGetLastError
   return hipStreamSynchronize(st);
 }
 
