@@ -83,6 +83,7 @@ class Config:
     QUEUE_TIMEOUT_MS = 200              # workers re-check their exit flag this often
     NATIVE_PREDICTOR = True             # ThreadPredictor's loop in native code (ga3c_pq_serve) when ZERO_COPY is on
     PIPELINED_PREDICTOR = True          # ... answering batch k beside the GPU's work on batch k+1 (ga3c_pq_serve_pipelined)
+    PIPELINED_FRAMES = False            # the same overlap for the frames loop (device frame queue): pays from ~500 agents per GPU on
     STATE_CACHE = True                  # the engine keeps the uint8 states its predictions read (a ring per agent in HBM) and
                                         # rollouts NAME their states (agent, request number) instead of carrying them: no second
                                         # trip over PCIe for training (needs ZERO_COPY, STATE_TRANSPORT = 'u8', the native

@@ -323,6 +323,11 @@ class Network:
         """(address of ga3c_net_serve_frames, engine handle): the callback of the native raw-frame predictor loop."""
         return C.cast(self._lib.ga3c_net_serve_frames, C.c_void_p).value, self._h
 
+    def frames_entries_pipelined(self):
+        """(addresses of ga3c_net_serve_frames_begin / _end, engine handle) for ga3c_pq_serve_frames_pipelined."""
+        return (C.cast(self._lib.ga3c_net_serve_frames_begin, C.c_void_p).value,
+                C.cast(self._lib.ga3c_net_serve_frames_end, C.c_void_p).value, self._h)
+
     def serve_frames(self, offsets, agents, flags):
         """push + predict of one popped batch in one GPU round trip (what the native loop calls); rows of requests that
         asked for no prediction come back as zeros."""
@@ -334,6 +339,26 @@ class Network:
         nat.check(self._lib.ga3c_net_serve_frames(self._h, nat.ptr(offsets, nat.i64p), nat.ptr(agents, nat.i32p),
                                                   nat.ptr(flags, nat.u32p), agents.size, nat.ptr(p), nat.ptr(v)),
                   "ga3c_net_serve_frames")
+        return [p, v]
+
+    def serve_frames_begin(self, offsets, agents, flags):
+        """First half of serve_frames (ga3c_net_serve_frames_begin): frames pushed, forward pass enqueued -> ticket."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        agents = np.ascontiguousarray(agents, dtype=np.int32)
+        flags = np.ascontiguousarray(flags, dtype=np.uint32)
+        ticket = C.c_int32(-1)
+        nat.check(self._lib.ga3c_net_serve_frames_begin(self._h, nat.ptr(offsets, nat.i64p), nat.ptr(agents, nat.i32p),
+                                                        nat.ptr(flags, nat.u32p), agents.size, C.byref(ticket)),
+                  "ga3c_net_serve_frames_begin")
+        return ticket.value
+
+    def serve_frames_end(self, ticket, flags):
+        """Second half (ga3c_net_serve_frames_end): waits for the batch begun under `ticket` -> [p, v] as serve_frames."""
+        flags = np.ascontiguousarray(flags, dtype=np.uint32)
+        p = np.zeros((flags.size, self.num_actions), dtype=np.float32)
+        v = np.zeros((flags.size,), dtype=np.float32)
+        nat.check(self._lib.ga3c_net_serve_frames_end(self._h, int(ticket), nat.ptr(flags, nat.u32p), flags.size, nat.ptr(p),
+                                                      nat.ptr(v)), "ga3c_net_serve_frames_end")
         return [p, v]
 
     def gather_entry(self):

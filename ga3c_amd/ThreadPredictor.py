@@ -11,6 +11,7 @@ With the zero-copy transport and a model that offers gather_entry() the loop its
 time slices of SERVE_SLICE_MS so that this thread holds the interpreter lock only to look at exit_flag and fold the
 counters; Config.NATIVE_PREDICTOR = False keeps the Python loop below.
 """
+import os
 import time
 from threading import Thread
 
@@ -67,8 +68,20 @@ class ThreadPredictor(Thread):
             fn, handle = entry()
             st = nat.ServeStats()
             self.native = True
+            # Config.PIPELINED_FRAMES: answering batch k beside the GPU's work on batch k+1, the model's call in two halves
+            # (ga3c_pq_serve_frames_pipelined; off by default -- it pays from ~500 agents per GPU on, DESIGN.md section 5;
+            # the helper-thread modes of GA3C_RESPONDER belong to the one-piece loop)
+            on = os.environ.get("GA3C_PIPELINE_FRAMES")
+            on = bool(int(on)) if on not in (None, "") else bool(getattr(Config, "PIPELINED_FRAMES", False))
+            split = getattr(model, "frames_entries_pipelined", None) if on else None
+            if split and os.environ.get("GA3C_RESPONDER", "0") not in ("0", "3", ""):
+                split = None
+            halves = split() if split else None
             while not self.exit_flag:
-                rc = t.serve_frames(fn, handle, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+                if halves:
+                    rc = t.serve_frames_pipelined(halves[0], halves[1], halves[2], Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
+                else:
+                    rc = t.serve_frames(fn, handle, Config.PREDICTION_BATCH_SIZE, SERVE_SLICE_MS, st)
                 self.batches, self.served = st.batches, st.served
                 self.seconds = {"pop": st.ns_pop * 1e-9, "predict": st.ns_predict * 1e-9, "respond": st.ns_respond * 1e-9}
                 if rc < 0:

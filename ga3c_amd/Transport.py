@@ -180,6 +180,13 @@ class Transport:
         rc = self._lib.ga3c_pq_serve_frames(self._h, entry, net_handle, int(max_batch), int(slice_ms), C.addressof(stats))
         return nat.check_host(rc, "ga3c_pq_serve_frames")
 
+    def serve_frames_pipelined(self, begin, end, net_handle, max_batch, slice_ms, stats):
+        """The same loop answering batch k beside the GPU's work on batch k+1 (ga3c_pq_serve_frames_pipelined); `begin` /
+        `end` are the addresses of ga3c_net_serve_frames_begin / _end."""
+        rc = self._lib.ga3c_pq_serve_frames_pipelined(self._h, begin, end, net_handle, int(max_batch), int(slice_ms),
+                                                      C.addressof(stats))
+        return nat.check_host(rc, "ga3c_pq_serve_frames_pipelined")
+
     # ---- training queue
     def rollout_views(self, slot):
         base = self._ro_off0 + slot * self._ro_stride

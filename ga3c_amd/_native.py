@@ -81,6 +81,8 @@ HIP_SIGNATURES = {
     "ga3c_net_frames_push": (C.c_int, [C.c_void_p, u8p, i32p, u8p, C.c_int32, i64p]),
     "ga3c_net_frames_push_offsets": (C.c_int, [C.c_void_p, i64p, i32p, u8p, C.c_int32, i64p]),
     "ga3c_net_serve_frames": (C.c_int, [C.c_void_p, i64p, i32p, u32p, C.c_int32, f32p, f32p]),
+    "ga3c_net_serve_frames_begin": (C.c_int, [C.c_void_p, i64p, i32p, u32p, C.c_int32, i32p]),
+    "ga3c_net_serve_frames_end": (C.c_int, [C.c_void_p, C.c_int32, u32p, C.c_int32, f32p, f32p]),
     "ga3c_net_train_frames": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_train_cached": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, C.c_float, f32p]),
     "ga3c_net_evaluate_cached": (C.c_int, [C.c_void_p, i32p, i64p, f32p, f32p, C.c_int32, C.c_float, f32p, f32p, f32p, f32p]),
@@ -148,6 +150,7 @@ HOST_SIGNATURES = {
     "ga3c_pq_round_trip": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.c_double,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "ga3c_pq_serve_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "ga3c_pq_serve_frames_pipelined": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_pq_serve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "ga3c_tq_acquire": (C.c_int, [C.c_void_p, C.c_int32]),
     "ga3c_tq_states": (C.c_void_p, [C.c_void_p, C.c_int32]),

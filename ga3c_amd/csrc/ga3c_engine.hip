@@ -150,6 +150,7 @@ struct Lane {
   bool shared_st = false;     // another lane enqueues on `st` too: completion is waited for on `done`, not on the stream
   int sidx = 0;               // which of the prediction streams `st` is (index into ga3c_net::stream_busy)
   std::atomic<bool> begun{false};   // taken by ga3c_net_predict_gather_begin, to be given back by _end
+  int frames_want = 0;              // ga3c_net_serve_frames_begin: predictions enqueued for the batch _end will hand out
   int64_t* cache_dst = nullptr;     // pinned [maxB]: byte offsets into the state cache of the batch begun with _begin_cached
   bool cache_on = false;
   hipEvent_t done = nullptr;
@@ -2243,35 +2244,42 @@ int ga3c_net_predict_frames(ga3c_net* net, const int32_t* agents, int32_t n, flo
   return finish_predict(net, L, n, STEP_QUEUES, p, v, z);
 }
 
-int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
-                          float* p, float* v) {
-  if (!net || !offsets || !agents || !flags || !p || !v) return fail(GA3C_EINVAL, "null argument");
+// One batch of the frames predictor loop, in two halves: _begin pushes the batch's frames into the agents' queues and enqueues
+// the forward pass for those that asked for one (the lane stays taken), _end waits for it and hands the answers out.  The
+// native loop (ga3c_pq_serve_frames_pipelined) answers batch k between the two halves of batch k+1.
+int ga3c_net_serve_frames_begin(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
+                                int32_t* ticket) {
+  if (!net || !offsets || !agents || !flags || !ticket) return fail(GA3C_EINVAL, "null argument");
   Frames& f = net->fr;
   if (!f.on) return fail(GA3C_ESTATE, "frames: call ga3c_net_frames_config first");
   if (!net->reg_dev) return fail(GA3C_ESTATE, "no host segment registered (ga3c_net_register_host)");
   if (n < 1 || n > f.maxA || n > net->maxB) return fail(GA3C_EINVAL, "frames: %d requests outside [1,%d]", n, f.maxA < net->maxB ? f.maxA : net->maxB);
   HIPCHK(hipSetDevice(net->cfg.device));
-  PredictInFlight inflight(net);
-  Lane* L = take_lane(net);
-  LaneGuard guard(net, L);
+  Lane* L = take_lane(net);                                  // stays taken until ga3c_net_serve_frames_end
+  net->predict_inflight.fetch_add(1, std::memory_order_relaxed);
+  auto give_back = [&]() {
+    net->predict_inflight.fetch_sub(1, std::memory_order_relaxed);
+    net->stream_busy[L->sidx].fetch_sub(1, std::memory_order_relaxed);
+    L->mu.unlock();
+  };
   // per-call argument arrays, carved out of the lane's (otherwise idle) pinned input staging and read by the kernels in place
   int32_t* h_ag = reinterpret_cast<int32_t*>(L->h_in);
   int32_t* h_slot = h_ag + net->maxB;
   int64_t* h_src = reinterpret_cast<int64_t*>(h_slot + net->maxB);
   uint8_t* h_reset = reinterpret_cast<uint8_t*>(h_src + net->maxB);
-  int want = 0;
+  int want = 0, rc = GA3C_OK;
   {
     std::lock_guard<std::mutex> g(f.mu);   // host mirrors of the queues; per agent the protocol allows one request in flight
     std::vector<uint8_t> seen((size_t)f.maxA, 0);
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n && rc == GA3C_OK; ++i) {
       const int a = agents[i];
-      if (a < 0 || a >= f.maxA) return fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", a, f.maxA);
-      if (seen[a]) return fail(GA3C_EINVAL, "frames: agent %d appears twice in one batch", a);
-      if (offsets[i] < 0 || offsets[i] + (int64_t)f.frame_bytes > net->reg_bytes || (offsets[i] & 3))
-        return fail(GA3C_EINVAL, "frame %d: offset %lld outside the registered segment or not 4-byte aligned", i, (long long)offsets[i]);
-      seen[a] = 1;
+      if (a < 0 || a >= f.maxA) rc = fail(GA3C_EINVAL, "frames: agent %d outside [0,%d)", a, f.maxA);
+      else if (seen[a]) rc = fail(GA3C_EINVAL, "frames: agent %d appears twice in one batch", a);
+      else if (offsets[i] < 0 || offsets[i] + (int64_t)f.frame_bytes > net->reg_bytes || (offsets[i] & 3))
+        rc = fail(GA3C_EINVAL, "frame %d: offset %lld outside the registered segment or not 4-byte aligned", i, (long long)offsets[i]);
+      else seen[a] = 1;
     }
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n && rc == GA3C_OK; ++i) {
       const int a = agents[i];
       const bool rs = (flags[i] & 1u) != 0;
       h_ag[i] = a; h_src[i] = offsets[i]; h_reset[i] = rs ? 1 : 0;
@@ -2280,32 +2288,72 @@ int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* 
       int& d = f.filled[a];
       d = rs ? 1 : (d < CIN ? d + 1 : CIN);
       if (!(flags[i] & 2u)) {
-        if (d < CIN) return fail(GA3C_ESTATE, "frames: agent %d asks for a prediction with %d of %d frames queued", a, d, CIN);
-        L->h_off[want++] = (int64_t)a * XS;
+        if (d < CIN) rc = fail(GA3C_ESTATE, "frames: agent %d asks for a prediction with %d of %d frames queued", a, d, CIN);
+        else L->h_off[want++] = (int64_t)a * XS;
       }
     }
   }
-  CHK(launch_frames(net, net->reg_dev, h_ag, h_reset, nullptr, n, h_src, L->st, h_slot));   // same stream as the forward pass
-  if (want == 0) return lane_wait(L);
-  const int A = net->A;
-  float* hp = L->h_out;
-  float* hv = hp + (size_t)net->maxB * A;
-  TraceRange range("ga3c.predict_frames");
-  const int64_t t0 = now_ns();
-  CHK(lane_forward(net, *L, want, STEP_QUEUES, hp, hv));
-  const int64_t t1 = now_ns();
-  CHK(lane_wait_step(L));
-  note_predict_span(net, L);
-  stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
-  stat_add(net, GA3C_STAT_PREDICT_ROWS, want);
-  stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, t1 - t0);
-  stat_add(net, GA3C_STAT_PREDICT_SYNC_NS, now_ns() - t1);
-  for (int i = 0, k = 0; i < n; ++i) {
-    if (flags[i] & 2u) continue;
-    memcpy(p + (size_t)i * A, hp + (size_t)k * A, (size_t)A * sizeof(float));
-    v[i] = hv[k++];
+  if (rc == GA3C_OK) rc = launch_frames(net, net->reg_dev, h_ag, h_reset, nullptr, n, h_src, L->st, h_slot);   // same stream as the forward pass
+  if (rc == GA3C_OK) {
+    if (want == 0) {
+      if (hipEventRecord(L->done, L->st) != hipSuccess) rc = fail(GA3C_EHIP, "hipEventRecord failed behind a batch of frames");
+    } else {
+      TraceRange range("ga3c.predict_frames");
+      const int64_t t0 = now_ns();
+      float* hp = L->h_out;
+      rc = lane_forward(net, *L, want, STEP_QUEUES, hp, hp + (size_t)net->maxB * net->A);   // leaves L->done behind the step
+      stat_add(net, GA3C_STAT_PREDICT_LAUNCH_NS, now_ns() - t0);
+    }
   }
+  if (rc != GA3C_OK) {
+    give_back();
+    return rc;
+  }
+  L->frames_want = want;
+  for (size_t i = 0; i < net->lanes.size(); ++i)
+    if (net->lanes[i] == L) *ticket = (int32_t)i;
+  L->begun.store(true);
   return GA3C_OK;
+}
+
+int ga3c_net_serve_frames_end(ga3c_net* net, int32_t ticket, const uint32_t* flags, int32_t n, float* p, float* v) {
+  if (!net || !flags || !p || !v) return fail(GA3C_EINVAL, "null argument");
+  if (ticket < 0 || ticket >= (int32_t)net->lanes.size()) return fail(GA3C_EINVAL, "bad ticket %d", ticket);
+  if (n < 1 || n > net->maxB) return fail(GA3C_EINVAL, "frames: %d requests outside [1,%d]", n, net->maxB);
+  Lane* L = net->lanes[(size_t)ticket];
+  if (!L->begun.exchange(false)) return fail(GA3C_ESTATE, "ticket %d: no batch was begun on that lane (or it was ended already)", ticket);
+  const int64_t t0 = now_ns();
+  const hipError_t he = hipEventSynchronize(L->done);      // left behind the batch by _begin
+  int rc = he == hipSuccess ? GA3C_OK : fail(GA3C_EHIP, "hipEventSynchronize failed: %s", hipGetErrorString(he));
+  const int want = L->frames_want;
+  if (rc == GA3C_OK && want > 0) {
+    note_predict_span(net, L);
+    const int A = net->A;
+    const float* hp = L->h_out;
+    const float* hv = hp + (size_t)net->maxB * A;
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+      if (flags[i] & 2u) continue;
+      if (k >= want) { rc = fail(GA3C_EINVAL, "frames: the flags ask for more predictions than the batch was begun with (%d)", want); break; }
+      memcpy(p + (size_t)i * A, hp + (size_t)k * A, (size_t)A * sizeof(float));
+      v[i] = hv[k++];
+    }
+    stat_add(net, GA3C_STAT_PREDICT_CALLS, 1);
+    stat_add(net, GA3C_STAT_PREDICT_ROWS, want);
+    stat_add(net, GA3C_STAT_PREDICT_SYNC_NS, now_ns() - t0);
+  }
+  net->predict_inflight.fetch_sub(1, std::memory_order_relaxed);
+  net->stream_busy[L->sidx].fetch_sub(1, std::memory_order_relaxed);
+  L->mu.unlock();
+  return rc;
+}
+
+int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
+                          float* p, float* v) {
+  if (!p || !v) return fail(GA3C_EINVAL, "null argument");
+  int32_t ticket = -1;
+  CHK(ga3c_net_serve_frames_begin(net, offsets, agents, flags, n, &ticket));
+  return ga3c_net_serve_frames_end(net, ticket, flags, n, p, v);
 }
 
 // rows named by (agent, plane sequence number) re-assembled from the plane history into train lane `t` (its mutex held)

@@ -1199,6 +1199,98 @@ int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, i
   }
 }
 
+int ga3c_pq_serve_frames_pipelined(ga3c_shm* shm, ga3c_serve_frames_begin_fn begin, ga3c_serve_frames_end_fn end, void* net,
+                                   int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* st) {
+  if (!shm || !begin || !end || !st || max_batch < 1 || slice_ms < 1) return fail(GA3C_H_EINVAL, "bad argument");
+  Header* h = shm->hdr();
+  const int A = h->cfg.num_actions;
+  // `cur` is on the GPU while `prev` (results already fetched) is answered
+  std::vector<uint32_t> ids[2] = {std::vector<uint32_t>((size_t)max_batch), std::vector<uint32_t>((size_t)max_batch)};
+  std::vector<float> p[2] = {std::vector<float>((size_t)max_batch * A, 0.f), std::vector<float>((size_t)max_batch * A, 0.f)};
+  std::vector<float> v[2] = {std::vector<float>((size_t)max_batch, 0.f), std::vector<float>((size_t)max_batch, 0.f)};
+  std::vector<uint32_t> flags((size_t)max_batch);
+  std::vector<int32_t> agents((size_t)max_batch);
+  std::vector<int64_t> offs((size_t)max_batch);
+  const int64_t t_end = now_ns() + (int64_t)slice_ms * 1000000;
+  name_this_thread("ga3c-predict");
+  const bool at_once = responder_mode() == 3;                // answer a batch before the next pop
+  // The held batch is answered beside the next one only when that next one is worth it: requests for at least `deep` rows
+  // are already queued (half a full batch; GA3C_PIPELINE_MIN_QUEUED).  With fewer the held answers go out first and the
+  // loop then sleeps for requests -- otherwise a closed population of agents splits into twice as many, half as large
+  // batches (256 native agents: 41 rows instead of 126), and what the overlap gives the fixed cost per batch takes back.
+  int deep = max_batch / 2;
+  if (const char* e = getenv("GA3C_PIPELINE_MIN_QUEUED")) deep = atoi(e);
+  int cur = 0, n_prev = 0;
+  auto answer_prev = [&]() -> int {
+    if (n_prev == 0) return GA3C_H_OK;
+    const int64_t t0 = now_ns();
+    const int rr = ga3c_pq_respond(shm, ids[1 - cur].data(), n_prev, p[1 - cur].data(), v[1 - cur].data());
+    st->ns_respond += now_ns() - t0;
+    n_prev = 0;
+    return rr;
+  };
+  for (;;) {
+    const int64_t t0 = now_ns();
+    const int64_t left_ms = (t_end - t0 + 999999) / 1000000;
+    if (left_ms <= 0) return answer_prev();                  // nothing is held across slices
+    if (n_prev && (int)ring_size(&h->req) < deep) {
+      const int rr = answer_prev();
+      if (rr < 0) return rr;
+    }
+    const int64_t t0b = now_ns();
+    const int n = ga3c_pq_pop_batch(shm, ids[cur].data(), max_batch, n_prev ? 0 : (int)left_ms);
+    const int64_t t1 = now_ns();
+    st->ns_pop += t1 - t0b;
+    if (n < 0 && n != GA3C_H_ETIMEOUT) {
+      (void)answer_prev();
+      return n;
+    }
+    int ticket = -1, predicted = 0;
+    if (n > 0) {
+      for (int i = 0; i < n; ++i) {
+        if (ids[cur][i] >= (uint32_t)h->cfg.max_agents) {
+          (void)answer_prev();
+          return fail(GA3C_H_EINVAL, "agent id %u out of range", ids[cur][i]);
+        }
+        offs[i] = h->agents_off + (int64_t)ids[cur][i] * h->agent_stride;
+        agents[i] = (int32_t)ids[cur][i];
+        flags[i] = shm->meta((int)ids[cur][i])->req_flags;
+        predicted += (flags[i] & GA3C_REQ_NO_PREDICT) ? 0 : 1;
+      }
+      const int rc = begin(net, offs.data(), agents.data(), flags.data(), n, &ticket);
+      if (rc < 0) {
+        (void)answer_prev();
+        return fail(GA3C_H_ECALLBACK, "serve callback (begin) failed with %d on a batch of %d", rc, n);
+      }
+    }
+    const int64_t t2 = now_ns();
+    st->ns_predict += t2 - t1;
+    const int rr = answer_prev();                            // beside the GPU's work on `cur`
+    if (n > 0) {
+      const int64_t t3 = now_ns();
+      const int rc = end(net, ticket, flags.data(), n, p[cur].data(), v[cur].data());
+      st->ns_predict += now_ns() - t3;
+      if (rc < 0) return fail(GA3C_H_ECALLBACK, "serve callback (end) failed with %d on a batch of %d", rc, n);
+      st->batches += 1;
+      st->served += predicted;
+      if (n > st->largest_batch) st->largest_batch = n;
+      if (at_once) {
+        const int64_t t4 = now_ns();
+        const int r3 = ga3c_pq_respond(shm, ids[cur].data(), n, p[cur].data(), v[cur].data());
+        st->ns_respond += now_ns() - t4;
+        if (r3 < 0) return r3;
+      } else {
+        n_prev = n;
+        cur = 1 - cur;
+      }
+    }
+    if (rr < 0) {
+      (void)answer_prev();
+      return rr;
+    }
+  }
+}
+
 int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms) {
   if (!shm) return fail(GA3C_H_EINVAL, "null argument");
   uint32_t slot = 0;

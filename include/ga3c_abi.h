@@ -235,6 +235,13 @@ int ga3c_net_frames_push_offsets(ga3c_net* net, const int64_t* offsets, const in
  * that asked for a prediction.  This is the callback of the native predictor loop ga3c_pq_serve_frames. */
 int ga3c_net_serve_frames(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
                           float* p, float* v);
+/* The same batch in two halves, for a loop that answers batch k while the GPU works on batch k + 1 (ga3c_pq_serve_frames_pipelined;
+ * ThreadPredictor.py:45-66 is one loop: predict, then scatter): _begin pushes the frames and enqueues the forward pass, and
+ * keeps the prediction lane it took (*ticket names it); _end (same n and flags) waits for the batch and fills p / v as
+ * ga3c_net_serve_frames does.  Every _begin must be followed by its _end; ga3c_net_serve_frames is the two back to back. */
+int ga3c_net_serve_frames_begin(ga3c_net* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags, int32_t n,
+                                int32_t* ticket);
+int ga3c_net_serve_frames_end(ga3c_net* net, int32_t ticket, const uint32_t* flags, int32_t n, float* p, float* v);
 int ga3c_net_train_frames(ga3c_net* net, const int32_t* agents, const int64_t* seqs, const float* y_r, const float* a,
                           int32_t batch, float learning_rate, float beta, float* losses);
 /* ga3c_net_evaluate for rows named by (agent, plane sequence number), as ga3c_net_train_frames takes them. */

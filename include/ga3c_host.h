@@ -183,6 +183,17 @@ typedef int (*ga3c_serve_frames_fn)(void* net, const int64_t* offsets, const int
                                     int32_t n, float* p, float* v);
 int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, int32_t max_batch, int32_t slice_ms,
                          ga3c_serve_stats* stats);
+/* ... and with the engine's call in two halves (ga3c_net_serve_frames_begin / _end): the loop pops batch k + 1, begins it,
+ * answers batch k -- a system call per sleeping agent, ~1.2 us a row, beside the GPU's work on k + 1 instead of in front of
+ * it -- and ends k + 1, but only when requests for at least half of max_batch are already queued (GA3C_PIPELINE_MIN_QUEUED):
+ * with fewer the held answers go out first, as in the loop above -- a small closed population of agents would otherwise
+ * travel as twice as many, half as large batches.  With a batch waiting to be answered only requests that are already
+ * queued are popped.  What the loop holds is answered before it returns; GA3C_RESPONDER = 3 answers every batch at once. */
+typedef int (*ga3c_serve_frames_begin_fn)(void* net, const int64_t* offsets, const int32_t* agents, const uint32_t* flags,
+                                          int32_t n, int32_t* ticket);
+typedef int (*ga3c_serve_frames_end_fn)(void* net, int32_t ticket, const uint32_t* flags, int32_t n, float* p, float* v);
+int ga3c_pq_serve_frames_pipelined(ga3c_shm* shm, ga3c_serve_frames_begin_fn begin, ga3c_serve_frames_end_fn end, void* net,
+                                   int32_t max_batch, int32_t slice_ms, ga3c_serve_stats* stats);
 
 /* training queue: agent side (ProcessAgent.py:175), trainer side (ThreadTrainer.py:49-59) */
 int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms);                 /* -> free slot id */

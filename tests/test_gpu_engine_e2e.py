@@ -449,15 +449,21 @@ def test_engine_on_raw_frames(tmp_path, monkeypatch, frontend):
         srv.model.close()
 
 
-@pytest.mark.parametrize("helper", ["1", "0"])
+@pytest.mark.parametrize("helper", ["1", "0", "pipelined"])
 def test_engine_on_planes_with_the_frame_queue_on_the_device(tmp_path, monkeypatch, helper):
     """FRAME_SOURCE = 'planes', FRONTEND = 'device': agents ship their newest 84x84 plane (7,056 B per step), the frame queues
     and the plane history live in HBM, rollouts name their states by (agent, plane).  helper: the answers of a batch are
-    given by the serve loop's helper thread (default) or by the loop itself (GA3C_RESPONDER=0)."""
+    given by the serve loop's helper thread (round 3's default), by the loop itself (GA3C_RESPONDER=0, the default), or by
+    the loop between the two halves of the next batch (Config.PIPELINED_FRAMES, overlap from two queued requests on)."""
     import ga3c_amd  # noqa: F401
     from Config import Config
     monkeypatch.chdir(tmp_path)
-    monkeypatch.setenv("GA3C_RESPONDER", helper)
+    if helper == "pipelined":
+        monkeypatch.setenv("GA3C_RESPONDER", "0")
+        monkeypatch.setenv("GA3C_PIPELINE_MIN_QUEUED", "2")
+        monkeypatch.setattr(Config, "PIPELINED_FRAMES", True)
+    else:
+        monkeypatch.setenv("GA3C_RESPONDER", helper)
     for k, v in dict(AGENTS=6, PREDICTORS=2, TRAINERS=1, SYNTHETIC_EPISODE_LENGTH=40, TIME_MAX=5, DYNAMIC_SETTINGS=False,
                      SAVE_MODELS=False, TRAINING_MIN_BATCH_SIZE=11, NUM_ACTIONS=6, PREDICTION_BATCH_SIZE=32,
                      FRAME_SOURCE='planes', FRONTEND='device').items():

@@ -304,8 +304,27 @@ def test_serve_frames_is_push_plus_predict_in_one_round_trip(net):
                 s1, d1 = net.frame_state(a)
                 s2, d2 = other.frame_state(a)
                 assert d1 == d2 and ((s1 is None and s2 is None) or np.array_equal(s1, s2))
+        # the call in two halves, two batches in flight on the net's two lanes (ga3c_pq_serve_frames_pipelined answers one
+        # batch between the halves of the next): agents 1, 4 | 6, 3, ended in the other order; same bits as one call
+        rgb = atari_like(rng, 4)
+        for k, a in enumerate(ids):
+            t.state_view(a)[:210 * 160 * 3] = rgb[k].reshape(-1)
+            t2.state_view(a)[:210 * 160 * 3] = rgb[k].reshape(-1)
+        flags = np.array([0, tp.REQ_NO_PREDICT, 0, 0], np.uint32)
+        ta = net.serve_frames_begin(offs[:2], ids[:2], flags[:2])
+        tb = net.serve_frames_begin(offs[2:], ids[2:], flags[2:])
+        assert ta != tb
+        pb, vb = net.serve_frames_end(tb, flags[2:])
+        pa, va = net.serve_frames_end(ta, flags[:2])
+        p2, v2 = other.serve_frames(offs, ids, flags)
+        assert np.array_equal(np.concatenate([pa, pb]), p2) and np.array_equal(np.concatenate([va, vb]), v2)
+        assert not pa[1].any() and p2[0].any()
+        with pytest.raises(RuntimeError, match="no batch was begun"):
+            net.serve_frames_end(ta, flags[:2])
         with pytest.raises(RuntimeError, match="asks for a prediction with"):
             net.serve_frames(offs[:1], np.array([7], np.int32), np.array([tp.REQ_RESET], np.uint32))
+        p, v = net.serve_frames(offs, ids, np.zeros(4, np.uint32))             # the lanes were given back: the net still serves
+        assert p.shape == (4, 6) and np.isfinite(p).all()
     finally:
         for m in (net, other):
             m.unregister_transport()

@@ -785,6 +785,73 @@ def test_cached_serve_loop_names_every_row_by_agent_and_request_number(mods):
         t.close()
 
 
+def test_pipelined_frames_loop_answers_a_batch_between_the_halves_of_the_next(mods, monkeypatch):
+    """ga3c_pq_serve_frames_pipelined: offsets, agent ids and request flags reach `begin`, `end` gets the same flags and the
+    ticket, every agent gets its own answer -- and a batch is answered only after the next one has been begun (that is the
+    overlap); what the loop holds when its slice ends is answered before it returns; GA3C_RESPONDER = 3 answers at once."""
+    import ctypes as C
+    nat, tp, Config = mods
+    t = tp.Transport.create(tp.unique_name("t_fpipe"), 6, 6, 64, 4, 6)
+    log, held, more = [], {}, []
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_int32))
+    def begin(net, offsets, agents, flags, n, ticket):
+        while more:
+            t.submit(more.pop(0))
+        rows = [(int(agents[i]), int(flags[i]), int(offsets[i])) for i in range(n)]
+        ticket[0] = len(log)
+        held[len(log)] = rows
+        log.append(("begin", rows, [a for a in range(6) if t.agent_idle(a)]))
+        return 0
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float))
+    def end(net, ticket, flags, n, p, v):
+        rows = held.pop(ticket)
+        assert n == len(rows) and [int(flags[i]) for i in range(n)] == [f for _, f, _ in rows]
+        for i, (ag, fl, _) in enumerate(rows):
+            v[i] = 100.0 + ag
+            for a in range(6):
+                p[i * 6 + a] = float(ag) if not fl & tp.REQ_NO_PREDICT else -1.0
+        log.append(("end", [ag for ag, _, _ in rows]))
+        return 0
+
+    b, e = C.cast(begin, C.c_void_p).value, C.cast(end, C.c_void_p).value
+    try:
+        st = nat.ServeStats()
+        assert t.submit(0) == 0 and t.submit(3, tp.REQ_RESET | tp.REQ_NO_PREDICT) == 0
+        assert t.serve_frames_pipelined(b, e, None, 8, 20, st) == 0          # one batch, answered when the slice ends
+        assert t.agent_idle(0) and t.agent_idle(3)
+        assert log[0][0] == "begin" and sorted((ag, fl) for ag, fl, _ in log[0][1]) == [(0, 0), (3, 3)]
+        assert all(off == t.state_offsets(np.array([ag], np.uint32))[0] for ag, _, off in log[0][1])
+        assert t.wait(0, 100)[2] == 100.0 and t.wait(3, 100)[1].tolist() == [-1.0] * 6
+        assert (st.batches, st.served) == (1, 1)                             # served counts predictions, not pushes
+        del log[:]
+        # a second batch arrives while the first is held: the first is answered only after the second was begun
+        monkeypatch.setenv("GA3C_PIPELINE_MIN_QUEUED", "2")                  # two queued requests are worth the overlap
+        assert t.submit(1) == 0
+        more.extend([2, 4])                                                  # (queued from inside the first batch's `begin`)
+        assert t.serve_frames_pipelined(b, e, None, 8, 50, st) == 0
+        kinds = [(k[0], sorted(r[0] for r in k[1]) if k[0] == "begin" else sorted(k[1])) for k in log]
+        assert kinds == [("begin", [1]), ("end", [1]), ("begin", [2, 4]), ("end", [2, 4])]
+        assert 1 not in log[2][2]                                             # agent 1 had no answer yet when batch 2 began
+        for a in (1, 2, 4):
+            rc, p, v = t.wait(a, 100)
+            assert rc == 0 and v == 100.0 + a and p.tolist() == [float(a)] * 6
+        assert (st.batches, st.served, st.largest_batch) == (3, 4, 2)
+        # the default asks for half a full batch (4 of 8) to be queued: with two, the held answer goes out first
+        monkeypatch.delenv("GA3C_PIPELINE_MIN_QUEUED")
+        del log[:]
+        assert t.submit(1) == 0
+        more.extend([2, 4])
+        assert t.serve_frames_pipelined(b, e, None, 8, 50, st) == 0
+        assert [k[0] for k in log] == ["begin", "end", "begin", "end"] and 1 in log[2][2]
+        for a in (1, 2, 4):
+            assert t.wait(a, 100)[0] == 0
+    finally:
+        t.shutdown()
+        t.close()
+
+
 def test_pipelined_serve_loop_reports_a_failing_engine_and_still_answers_what_it_holds(mods):
     import ctypes as C
     nat, tp, Config = mods
