@@ -87,7 +87,7 @@ struct Ring {
   alignas(64) std::atomic<uint32_t> signal;   // bumped on every push; the futex word consumers sleep on
   std::atomic<uint32_t> waiters;
   uint32_t mask;
-  uint32_t pad;
+  std::atomic<uint32_t> wake_claim;  // 1 while a wake-up of a sleeping consumer is under way: further pushes make no system call
   int64_t cells_off;   // byte offset of the cell array from the segment base
 };
 
@@ -98,6 +98,7 @@ void ring_init(char* base, Ring* r, uint32_t cap_pow2, int64_t cells_off) {
   r->deq.store(0);
   r->signal.store(0);
   r->waiters.store(0);
+  r->wake_claim.store(0);
   r->mask = cap_pow2 - 1;
   r->cells_off = cells_off;
   Cell* c = cells(base, r);
@@ -151,7 +152,14 @@ bool ring_push(char* base, Ring* r, uint32_t v, const std::atomic<uint32_t>* clo
   cell->data = v;
   cell->seq.store(pos + 1, std::memory_order_release);
   r->signal.fetch_add(1, std::memory_order_seq_cst);
-  if (r->waiters.load(std::memory_order_seq_cst) != 0) futex_wake(&r->signal, 1);
+  // One wake-up per sleeper, not one per push: a predictor's answers wake a hundred agents within microseconds, they all
+  // submit while the consumer they find asleep is still on its way out of FUTEX_WAIT (~4 us), and a FUTEX_WAKE from each of
+  // them is a hundred threads on one futex hash bucket's lock (measured: 7-10 cores of system time in the agents, `submit`
+  // 4-9 us instead of 0.8, the cgroup throttled).  The first push claims the wake-up; a consumer drops the claim when it is
+  // back from its wait and again before it goes to sleep, so a claim that found nobody asleep cannot outlive the next sleeper.
+  if (r->waiters.load(std::memory_order_seq_cst) != 0 && r->wake_claim.load(std::memory_order_seq_cst) == 0 &&
+      r->wake_claim.exchange(1, std::memory_order_seq_cst) == 0)
+    futex_wake(&r->signal, 1);
   return true;
 }
 
@@ -241,14 +249,22 @@ struct ga3c_shm {
 namespace {
 
 // Block until an item can be popped from `r`, the segment is closed, or the timeout passes.
-int ring_pop_wait(ga3c_shm* s, Ring* r, uint32_t* v, int timeout_ms) {
+// pass_on: a consumer that slept and then got an entry wakes the next sleeper if more entries are there -- for rings whose
+// consumers take ONE entry each (the free rollout slots: a trainer gives back two dozen at a time and its pushes wake one
+// agent, see ring_push); the rings drained by a batching thread leave the others asleep.
+int ring_pop_wait(ga3c_shm* s, Ring* r, uint32_t* v, int timeout_ms, bool pass_on = false) {
   Header* h = s->hdr();
   const int64_t deadline = timeout_ms >= 0 ? now_ms() + timeout_ms : -1;
+  bool slept = false;
   for (;;) {
-    if (ring_try_pop(s->base, r, v)) return GA3C_H_OK;
+    if (ring_try_pop(s->base, r, v)) {
+      if (pass_on && slept && r->waiters.load(std::memory_order_seq_cst) != 0 && ring_size(r) != 0) futex_wake(&r->signal, 1);
+      return GA3C_H_OK;
+    }
     if (h->closed.load(std::memory_order_acquire)) return GA3C_H_ECLOSED;
     const uint32_t sig = r->signal.load(std::memory_order_seq_cst);
     r->waiters.fetch_add(1, std::memory_order_seq_cst);
+    r->wake_claim.store(0, std::memory_order_seq_cst);      // whoever pushes from here on may wake this consumer
     int rc = GA3C_H_OK;
     if (ring_try_pop(s->base, r, v)) {
       r->waiters.fetch_sub(1, std::memory_order_seq_cst);
@@ -260,7 +276,8 @@ int ring_pop_wait(ga3c_shm* s, Ring* r, uint32_t* v, int timeout_ms) {
       if (left <= 0) rc = GA3C_H_ETIMEOUT;
       wait_ms = (int)left;
     }
-    if (rc == GA3C_H_OK) futex_wait(&r->signal, sig, wait_ms);
+    if (rc == GA3C_H_OK) { futex_wait(&r->signal, sig, wait_ms); slept = true; }
+    r->wake_claim.store(0, std::memory_order_seq_cst);
     r->waiters.fetch_sub(1, std::memory_order_seq_cst);
     if (rc != GA3C_H_OK) return rc;
   }
@@ -862,6 +879,8 @@ int ga3c_pq_pop_batch(ga3c_shm* shm, uint32_t* ids, int32_t max_ids, int32_t tim
   if (rc != GA3C_H_OK) return rc;
   int n = 1;
   while (n < max_ids && ring_try_pop(shm->base, &h->req, &ids[n])) ++n;
+  // (the pushes of a burst wake ONE sleeping consumer: if this batch is full and more is queued, the next one is woken here)
+  if (n == max_ids && h->req.waiters.load(std::memory_order_seq_cst) != 0 && ring_size(&h->req) != 0) futex_wake(&h->req.signal, 1);
   // optional linger (off by default: the reference drains without waiting, ThreadPredictor.py:54-55): keep collecting for
   // up to linger_us while fewer than linger_batch requests are in hand -- every forward pass has a fixed cost of tens
   // of microseconds, so a few more rows per pass can be worth a short wait
@@ -1294,7 +1313,7 @@ int ga3c_pq_serve_frames_pipelined(ga3c_shm* shm, ga3c_serve_frames_begin_fn beg
 int ga3c_tq_acquire(ga3c_shm* shm, int32_t timeout_ms) {
   if (!shm) return fail(GA3C_H_EINVAL, "null argument");
   uint32_t slot = 0;
-  const int rc = ring_pop_wait(shm, &shm->hdr()->freeq, &slot, timeout_ms);
+  const int rc = ring_pop_wait(shm, &shm->hdr()->freeq, &slot, timeout_ms, true);
   return rc == GA3C_H_OK ? (int)slot : rc;
 }
 
