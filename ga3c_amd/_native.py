@@ -146,6 +146,7 @@ HOST_SIGNATURES = {
     "ga3c_frame_preprocess": (C.c_int, [u8p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, u8p]),
     "ga3c_pq_set_linger": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "ga3c_pq_set_spin": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ga3c_host_signal_hold": (C.c_int, [C.c_int32]),
     "ga3c_pq_wake_latency": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ga3c_pq_round_trip": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint32, C.c_int32, C.c_int32, C.c_double,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

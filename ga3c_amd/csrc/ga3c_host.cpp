@@ -123,14 +123,21 @@ void ring_init(char* base, Ring* r, uint32_t cap_pow2, int64_t cells_off) {
 // (two rt_sigprocmask calls, ~0.2 us, against an agent step of ~28 us); SIGKILL cannot be held back and may still wedge
 // a ring -- the transport has to be recreated then.  On `closed` the cell is abandoned on purpose: every consumer treats
 // a closed segment as drained.
+// (ga3c_host_signal_hold(0) switches the mask off for a process whose producers are THREADS: rt_sigprocmask takes the
+// process's sighand lock, which its threads share -- 256 to 512 agent threads submitting a million times a second turned it
+// into 10-13 cores of system time; agent PROCESSES, the product's, have a lock each and keep the default.)
+std::atomic<int> g_signal_hold{1};
+
 struct SignalHold {
   sigset_t old;
-  SignalHold() {
+  bool on;
+  SignalHold() : on(g_signal_hold.load(std::memory_order_relaxed) != 0) {
+    if (!on) return;
     sigset_t all;
     sigfillset(&all);
     pthread_sigmask(SIG_BLOCK, &all, &old);
   }
-  ~SignalHold() { pthread_sigmask(SIG_SETMASK, &old, nullptr); }
+  ~SignalHold() { if (on) pthread_sigmask(SIG_SETMASK, &old, nullptr); }
 };
 
 bool ring_push(char* base, Ring* r, uint32_t v, const std::atomic<uint32_t>* closed) {
@@ -288,6 +295,11 @@ int ring_pop_wait(ga3c_shm* s, Ring* r, uint32_t* v, int timeout_ms, bool pass_o
 extern "C" {
 
 const char* ga3c_host_last_error(void) { return g_err.c_str(); }
+
+int ga3c_host_signal_hold(int32_t on) {
+  g_signal_hold.store(on ? 1 : 0, std::memory_order_relaxed);
+  return GA3C_H_OK;
+}
 
 int ga3c_returns_fork(const double* rewards, int32_t T, double gamma, double terminal_reward, int32_t discounting,
                       int32_t use_intermediate_reward, double* out) {

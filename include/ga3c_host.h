@@ -79,6 +79,11 @@ int ga3c_shm_shutdown(ga3c_shm* shm);      /* wakes every waiter with GA3C_H_ECL
 /* Removes the segment's NAME (owner only) and leaves every mapping alone: for a server that must end without unmapping --
  * the GPU may still be reading the registered segment -- and must not leave /dev/shm/ga3c_* behind. */
 int ga3c_shm_unlink(ga3c_shm* shm);
+/* Producers hold asynchronous signals back for the few instructions between taking a ring ticket and publishing the entry (an
+ * agent process ended with SIGTERM -- Server.remove_agent, ProcessAgent.py has no counterpart: its queues are pipes -- must
+ * not leave a ticket unfilled).  on = 0 switches that off for THIS process: for producers that are threads of one process,
+ * whose signal masks hang on one kernel lock (the native agent threads of tests/native/native_agents.cpp); default 1. */
+int ga3c_host_signal_hold(int32_t on);
 void* ga3c_shm_base(ga3c_shm* shm);
 int64_t ga3c_shm_bytes(ga3c_shm* shm);
 int ga3c_shm_get_config(ga3c_shm* shm, ga3c_shm_config* cfg);

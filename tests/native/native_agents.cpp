@@ -26,6 +26,7 @@ int main(int argc, char** argv) {
   const double seconds = atof(argv[3]);
   const bool train = atoi(argv[4]) != 0;
   ga3c_shm* shm = nullptr;
+  ga3c_host_signal_hold(0);                     // the agents here are threads: their signal masks share one kernel lock
   if (ga3c_shm_attach(name, &shm) != 0) { fprintf(stderr, "attach: %s\n", ga3c_host_last_error()); return 1; }
   ga3c_shm_config cfg;
   ga3c_shm_get_config(shm, &cfg);
