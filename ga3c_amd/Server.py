@@ -84,8 +84,11 @@ class Server:
             trainers = max(Config.TRAINERS, 2, 8 if Config.DYNAMIC_SETTINGS else 0)
             total = ((slots if slots > 0 else slot_count()) + 2) * (Config.TIME_MAX + 1) + 8 + \
                 trainers * (Config.TRAINING_MIN_BATCH_SIZE + Config.TIME_MAX + 1)
+            # (with the dynamic adjustment on the live agents can be a fraction of max_agents and each one's share of what is
+            # in flight that much larger: eight times the fair share then -- a 330-s soak at four lost one batch of 1.4 M)
+            share = 8 if Config.DYNAMIC_SETTINGS else 4
             depth = int(getattr(Config, "STATE_CACHE_DEPTH", 0)) or \
-                min(total, max(64, 4 * -(-total // self.max_agents) + 4 * (Config.TIME_MAX + 1)))
+                min(total, max(64, share * -(-total // self.max_agents) + 4 * (Config.TIME_MAX + 1)))
             try:
                 self.model.state_cache_config(self.max_agents, depth)
                 self.state_cache_depth = depth
