@@ -1246,10 +1246,10 @@ int ga3c_pq_serve_frames_pipelined(ga3c_shm* shm, ga3c_serve_frames_begin_fn beg
   name_this_thread("ga3c-predict");
   const bool at_once = responder_mode() == 3;                // answer a batch before the next pop
   // The held batch is answered beside the next one only when that next one is worth it: requests for at least `deep` rows
-  // are already queued (half a full batch; GA3C_PIPELINE_MIN_QUEUED).  With fewer the held answers go out first and the
-  // loop then sleeps for requests -- otherwise a closed population of agents splits into twice as many, half as large
+  // are already queued (a quarter of a full batch; GA3C_PIPELINE_MIN_QUEUED).  With fewer the held answers go out first and
+  // the loop then sleeps for requests -- otherwise a closed population of agents splits into twice as many, half as large
   // batches (256 native agents: 41 rows instead of 126), and what the overlap gives the fixed cost per batch takes back.
-  int deep = max_batch / 2;
+  int deep = max_batch / 4 > 1 ? max_batch / 4 : 1;
   if (const char* e = getenv("GA3C_PIPELINE_MIN_QUEUED")) deep = atoi(e);
   int cur = 0, n_prev = 0;
   auto answer_prev = [&]() -> int {

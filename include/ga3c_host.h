@@ -190,7 +190,7 @@ int ga3c_pq_serve_frames(ga3c_shm* shm, ga3c_serve_frames_fn serve, void* net, i
                          ga3c_serve_stats* stats);
 /* ... and with the engine's call in two halves (ga3c_net_serve_frames_begin / _end): the loop pops batch k + 1, begins it,
  * answers batch k -- a system call per sleeping agent, ~1.2 us a row, beside the GPU's work on k + 1 instead of in front of
- * it -- and ends k + 1, but only when requests for at least half of max_batch are already queued (GA3C_PIPELINE_MIN_QUEUED):
+ * it -- and ends k + 1, but only when requests for at least a quarter of max_batch are already queued (GA3C_PIPELINE_MIN_QUEUED):
  * with fewer the held answers go out first, as in the loop above -- a small closed population of agents would otherwise
  * travel as twice as many, half as large batches.  With a batch waiting to be answered only requests that are already
  * queued are popped.  What the loop holds is answered before it returns; GA3C_RESPONDER = 3 answers every batch at once. */

@@ -827,7 +827,7 @@ def test_pipelined_frames_loop_answers_a_batch_between_the_halves_of_the_next(mo
         assert (st.batches, st.served) == (1, 1)                             # served counts predictions, not pushes
         del log[:]
         # a second batch arrives while the first is held: the first is answered only after the second was begun
-        monkeypatch.setenv("GA3C_PIPELINE_MIN_QUEUED", "2")                  # two queued requests are worth the overlap
+        monkeypatch.delenv("GA3C_PIPELINE_MIN_QUEUED", raising=False)        # default: a quarter of a full batch = 2 of 8 queued
         assert t.submit(1) == 0
         more.extend([2, 4])                                                  # (queued from inside the first batch's `begin`)
         assert t.serve_frames_pipelined(b, e, None, 8, 50, st) == 0
@@ -838,8 +838,8 @@ def test_pipelined_frames_loop_answers_a_batch_between_the_halves_of_the_next(mo
             rc, p, v = t.wait(a, 100)
             assert rc == 0 and v == 100.0 + a and p.tolist() == [float(a)] * 6
         assert (st.batches, st.served, st.largest_batch) == (3, 4, 2)
-        # the default asks for half a full batch (4 of 8) to be queued: with two, the held answer goes out first
-        monkeypatch.delenv("GA3C_PIPELINE_MIN_QUEUED")
+        # asked to wait for four queued requests, the loop sends the held answer out first when there are two
+        monkeypatch.setenv("GA3C_PIPELINE_MIN_QUEUED", "4")
         del log[:]
         assert t.submit(1) == 0
         more.extend([2, 4])
