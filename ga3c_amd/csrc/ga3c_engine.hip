@@ -324,6 +324,8 @@ struct ga3c_net {
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
                                        // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
+  int c2dw_occ = 3;                    // conv2_dw at 129 .. 192 rows: workgroups per CU its registers are cut for (GA3C_C2DW_OCC=2: the
+                                       // 205-VGPR form at every size); elsewhere the grid takes as many rounds either way and the 2 form runs
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
   // State cache (ga3c_net_state_cache_config): the uint8 states the prediction steps read out of the transport, kept in HBM
   // in a ring of `depth` per agent, slot = request number % depth -- a train batch then names its rows (agent, request
@@ -347,6 +349,8 @@ struct ga3c_net {
                                        // predictions/s, 2 -> 5.81 / 7.79 / 9.01 / 10.60, 1 -> 5.55 / 7.78 / 8.98 / 10.59
   std::atomic<int> predict_inflight{0};
   bool d1f_tile = true;                // LDS-tiled dense1 forward where its grid is one round (GA3C_D1F_TILE=0: never)
+  bool d1b_tail = true;                // dense1_bwd_tile at 129 .. 133 rows: the rows past the first chunk wait in the LDS a chunk leaves free
+                                       // (D1B_TAIL_ROWS; GA3C_D1B_TAIL=0: a second round of staging loads, as for any larger batch)
   int d1b_tile_max = 1 << 30;          // largest batch that takes the LDS-tiled dense1 backward (GA3C_D1B_TILE_MAX overrides)
   bool graphs = false;                 // GA3C_GRAPHS=1: prediction steps replayed as hipGraphs.  Off by default: on ROCm 7.2 a
                                        // 4-kernel graph launch costs ~6 us MORE per step than four plain launches and
@@ -522,9 +526,11 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     d.hb = hb;
     d.upd = upd;
     d.role_blocks = A + 2 < 14 ? A + 2 : 14;       // 242 tiles + the roles stay within one round of workgroups on 256 CUs
-    if (upd.on && upd.defer_wd) hipLaunchKernelGGL(dense1_bwd_tile_kernel<2>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
-    else if (upd.on) hipLaunchKernelGGL(dense1_bwd_tile_kernel<1>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
-    else hipLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), st, d);
+    d.tail_lds = net->d1b_tail && B > D1B_ROWS && B <= D1B_ROWS + D1B_TAIL_ROWS;
+    const size_t d1b_lds = (d.tail_lds ? D1B_LDS_FLOATS_TAIL : D1B_LDS_FLOATS) * sizeof(float);
+    if (upd.on && upd.defer_wd) hipLaunchKernelGGL(dense1_bwd_tile_kernel<2>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
+    else if (upd.on) hipLaunchKernelGGL(dense1_bwd_tile_kernel<1>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
+    else hipLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
   } else {
     Dense1BwdArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
@@ -555,7 +561,8 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
     // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
-    hipLaunchKernelGGL(conv2_dw_kernel, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+    if (net->c2dw_occ >= 3 && B > 128 && B <= 192) hipLaunchKernelGGL(conv2_dw_kernel<3>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+    else hipLaunchKernelGGL(conv2_dw_kernel<2>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
     hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
     // workgroups = partial slabs.  Measured at batch 128 (round 2): 512 / 384 / 256 / 192 / 128 workgroups -> train step
     // 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
@@ -1462,9 +1469,11 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   net->fused_conv = getenv("GA3C_SPLIT_CONV") == nullptr;
   net->graphs = getenv("GA3C_GRAPHS") != nullptr;
   if (const char* e = getenv("GA3C_D1B_TILE_MAX")) net->d1b_tile_max = atoi(e);
+  if (const char* e = getenv("GA3C_D1B_TAIL")) net->d1b_tail = atoi(e) != 0;
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
   if (const char* e = getenv("GA3C_D1F_FRAG_LANES")) net->d1f_frag_lanes = atoi(e);
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_C2DW_OCC")) net->c2dw_occ = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
   if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
@@ -1491,7 +1500,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   }
   for (const void* fn : {reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<0>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<1>),
                          reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<2>)}) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS * sizeof(float)));
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS_TAIL * sizeof(float)));
     if (e != hipSuccess) {
       delete net;
       return fail(GA3C_EHIP, "cannot reserve LDS for dense1_bwd_tile_kernel: %s", hipGetErrorString(e));
@@ -2758,7 +2767,9 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "conv1_dw") {
       TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {
-      TL(conv2_dw_kernel, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
+      TL(conv2_dw_kernel<2>, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
+    } else if (k == "conv2_dw_occ3") {
+      TL(conv2_dw_kernel<3>, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
       hipExtLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, t.st, t.ev0, t.ev1, 0, t.dn2, net->theta_pk[net->latest] + PK_W2DX, t.f.n1, t.dn1, B);
     } else if (k == "dense1_dw") {
@@ -2790,15 +2801,16 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       hipExtLaunchKernelGGL((conv_bwd_kernel<false, true>), dim3(2 * B), dim3(1024), CB_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, t.f.n1, t.dn2, net->theta_pk[l] + PK_W2DX, t.dn1, t.slab2,
                             t.slab1, B, (const float*)(g + OFF_WD), fu);
-    } else if (k == "dense1_bwd_tile") {
+    } else if (k == "dense1_bwd_tile" || k == "dense1_bwd_tile_notail") {
       Dense1TileArgs d;
       d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
       d.hb.B = B; d.hb.A = net->A; d.hb.d1 = t.f.d1; d.hb.dz = t.dz; d.hb.dv = t.dv; d.hb.lossrow = t.lossrow;
       d.hb.g_wp = g + OFF_WP; d.hb.g_bp = g + off_bp(net->A); d.hb.g_wv = g + OFF_WV; d.hb.g_bv = g + OFF_BV; d.hb.losses = t.losses;
       d.role_blocks = net->A + 2 < 14 ? net->A + 2 : 14;
       memset(&d.upd, 0, sizeof d.upd);
-      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
-                            t.ev0, t.ev1, 0, d);
+      d.tail_lds = k == "dense1_bwd_tile" && net->d1b_tail && B > D1B_ROWS && B <= D1B_ROWS + D1B_TAIL_ROWS;
+      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024),
+                            (d.tail_lds ? D1B_LDS_FLOATS_TAIL : D1B_LDS_FLOATS) * sizeof(float), t.st, t.ev0, t.ev1, 0, d);
     } else if (k == "heads") {
       HeadArgs h;
       memset(&h, 0, sizeof h);

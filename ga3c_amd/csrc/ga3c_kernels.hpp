@@ -1175,6 +1175,9 @@ constexpr int SLAB2 = 256 * 32 + 32;
 constexpr int C2DW_IMG = C2_PW * C2_PW * C1;     // 9216 floats
 constexpr int C2DW_DN = 128 * C2;                // 4096 floats
 
+// PF: the next sample's loads are in flight during the MFMAs (52 VGPRs held across them); without, a sample's loads are
+// requested when its turn comes -- the form for grids that give every workgroup ONE sample (gx = B)
+template <bool PF = true>
 __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, const float* __restrict__ dn2,
                                                           float* __restrict__ part, int B, int bx, int by, int gx) {
   __shared__ __attribute__((aligned(16))) float lds[C2DW_IMG + C2DW_DN];
@@ -1203,15 +1206,16 @@ __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, cons
     }
   };
   int b = bx;
-  if (b < B) fetch(b);
+  if (PF && b < B) fetch(b);
   for (; b < B; b += gx) {
+    if (!PF) fetch(b);
     __syncthreads();                                   // everyone is done reading the previous sample
 #pragma unroll
     for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(&img[(threadIdx.x + 256 * i) * 4]) = simg[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&dnl[(threadIdx.x + 256 * i) * 4]) = sdn[i];
     __syncthreads();
-    if (b + gx < B) fetch(b + gx);
+    if (PF && b + gx < B) fetch(b + gx);
     // operands of step s+1 are fetched and pinned in registers of their own before the MFMAs of step s
     float oa[2][4], ob[2][4][2];
     auto load_step = [&](int s, float (&a)[4], float (&bb)[4][2]) {
@@ -1381,6 +1385,13 @@ constexpr int D1B_COLS = 16;                     // flat columns per workgroup
 constexpr int D1B_NS = D1B_ROWS + 4;             // row stride of the transposed flat columns [16][128] in LDS
 constexpr int D1B_LDS_FLOATS = D1B_ROWS * D1B_DS + D1B_COLS * D1B_DS + D1B_COLS * D1B_NS;   // 39552 floats = 158,208 B
 constexpr int D1B_TILES = FLAT / D1B_COLS;       // 242
+// Tail area: the 5,632 bytes a CU's LDS has left beside a chunk hold the dd1 rows and flat columns of up to 5 rows PAST the first
+// chunk (a "batch = 128" trainer assembles 129 .. 133 rows), requested together with the first chunk's staging loads; the
+// second chunk is then staged LDS -> LDS instead of waiting for a second memory round trip behind the first chunk's MFMAs.
+constexpr int D1B_TAIL_ROWS = 5;
+constexpr int D1B_TAIL_FLOATS = D1B_TAIL_ROWS * D1B_DS + D1B_TAIL_ROWS * D1B_COLS;          // 1380 floats
+constexpr int D1B_LDS_FLOATS_TAIL = D1B_LDS_FLOATS + D1B_TAIL_FLOATS;                       // 40932 floats = 163,728 B
+static_assert(D1B_LDS_FLOATS_TAIL * sizeof(float) <= 160 * 1024, "dense1_bwd_tile: the tail area must fit the CU's 160 KB");
 
 // head weight gradients / loss sums for a 1024-thread block (same arithmetic order as heads_bwd_role up to the fold width)
 template <bool UPD>
@@ -1448,6 +1459,7 @@ __device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int ro
 struct Dense1TileArgs {
   const float* n2; const float* dd1; const float* wd; float* g_wd; float* g_bd; float* dn2; int B;
   HeadBwdArgs hb; int role_blocks;
+  int tail_lds;      // the launch carries D1B_LDS_FLOATS_TAIL floats of LDS and D1B_ROWS < B <= D1B_ROWS + D1B_TAIL_ROWS
   FusedUpd upd;      // on: dense1/w, dense1/b and the head parameters are stepped here (see FusedUpd)
 };
 
@@ -1485,10 +1497,26 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     pre_ms = ld4(a.upd.ms + OFF_WD + uidx);
     pre_th = ld4(a.upd.tin + OFF_WD + uidx);
   }
+  float* tdd = d1b_lds + D1B_LDS_FLOATS;                         // [5][260]  dd1 rows 128.. (tail area, a.tail_lds only)
+  float* tn2 = tdd + D1B_TAIL_ROWS * D1B_DS;                     // [5][16]   their flat columns k0..k0+15
+  const bool tail = a.tail_lds != 0;                             // block-uniform
   for (int c0 = 0; c0 < B; c0 += D1B_ROWS) {
     const int rows = B - c0 < D1B_ROWS ? B - c0 : D1B_ROWS;      // real rows of this chunk
     const int prow = (rows + 15) & ~15;                          // padded to whole MFMA tiles
     if (c0) __syncthreads();                                     // everyone is done reading the previous chunk
+    if (c0 && tail) {
+      // ---- the second chunk out of the tail area: same images in dds / n2s as the loads below would leave
+      {
+        const int row = wv;                                      // prow = 16: one row per wave
+        *reinterpret_cast<f32x4*>(&dds[row * D1B_DS + 4 * lane]) = row < rows ? ld4(tdd + row * D1B_DS + 4 * lane) : zero4();
+      }
+      if (threadIdx.x < 4 * 16) {
+        const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+        const f32x4 v = row < rows ? ld4(tn2 + row * D1B_COLS + 4 * c) : zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) n2s[(4 * c + j) * D1B_NS + row] = v[j];
+      }
+    } else {
     // ---- stage: one 1 KB wave instruction per dd1 / Wd row, one per 16 rows of the flat columns
     for (int row = wv; row < prow; row += 16) {
       if (row < rows)
@@ -1500,11 +1528,20 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     if (c0 == 0)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wd + (size_t)(k0 + wv) * HID + 4 * lane),
                                        (__attribute__((address_space(3))) void*)(wds + wv * D1B_DS), 16, 0, 0);
+    if (c0 == 0 && tail) {                                       // rows 128.. : requested now, used by the second chunk
+      if (wv < B - D1B_ROWS)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dd1 + (size_t)(D1B_ROWS + wv) * HID + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(tdd + wv * D1B_DS), 16, 0, 0);
+    }
     if (threadIdx.x < 4 * D1B_ROWS) {                            // thread -> (row tid/4, float4 tid%4), stored transposed
       const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
       const f32x4 v = row < rows ? ld4(a.n2 + (size_t)(c0 + row) * FLAT + k0 + 4 * c) : zero4();
 #pragma unroll
       for (int j = 0; j < 4; ++j) n2s[(4 * c + j) * D1B_NS + row] = v[j];
+    } else if (c0 == 0 && tail && (int)threadIdx.x - 4 * D1B_ROWS < 4 * (B - D1B_ROWS)) {
+      const int i = threadIdx.x - 4 * D1B_ROWS, row = i >> 2, c = i & 3;   // waves 8..: the tail rows' flat columns, row-major
+      *reinterpret_cast<f32x4*>(&tn2[row * D1B_COLS + 4 * c]) = ld4(a.n2 + (size_t)(D1B_ROWS + row) * FLAT + k0 + 4 * c);
+    }
     }
     __syncthreads();                                             // vmcnt(0) precedes the barrier: the DMA has landed
     if (wv < 8) {
@@ -1662,9 +1699,14 @@ __global__ __launch_bounds__(256) void dense1_bwd_kernel(Dense1BwdArgs a) {
     else dense1_dx_body<1>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
   }
 }
-__global__ __launch_bounds__(256, 2) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
-                                                          float* __restrict__ part, int B) {
-  conv2_dw_body(n1, dn2, part, B, blockIdx.x, blockIdx.y, gridDim.x);
+// OCC = workgroups per CU the register budget is cut for.  2: 205 VGPRs, the grid of 4 B workgroups is one round up to 128 rows
+// (512 slots) and the 16 workgroups past it at 132 rows are a second round (6.1 -> 8.9 us).  3: <= 168 VGPRs (no loads held across
+// the MFMAs: conv2_dw_body<false>; the engine launches it with one sample per workgroup), three workgroups' LDS (3 x 53,248 B)
+// still fit a CU, one round up to 192 rows.  Same arithmetic, same bits.
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
+                                                            float* __restrict__ part, int B) {
+  conv2_dw_body<OCC == 2>(n1, dn2, part, B, blockIdx.x, blockIdx.y, gridDim.x);
 }
 __global__ __launch_bounds__(512) void conv2_dx_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
                                                        const float* __restrict__ n1, float* __restrict__ dn1, int B) {
