@@ -324,8 +324,9 @@ struct ga3c_net {
   bool fused_conv = true;              // conv1+conv2 in one launch (GA3C_SPLIT_CONV=1 selects the two-kernel form)
   bool fused_update = true;            // single-GPU train steps: RMSProp applied by the kernels that complete each gradient
                                        // element, no optimizer launch (GA3C_FUSED_UPDATE=0: the rmsprop kernel)
-  int c2dw_occ = 3;                    // conv2_dw at 129 .. 192 rows: workgroups per CU its registers are cut for (GA3C_C2DW_OCC=2: the
-                                       // 205-VGPR form at every size); elsewhere the grid takes as many rounds either way and the 2 form runs
+  int c2dw_occ = 3;                    // conv2_dw up to 256 rows (one sample per workgroup): workgroups per CU its registers are cut for
+                                       // (GA3C_C2DW_OCC=2: the 205-VGPR form with the next sample's loads in flight, which larger batches run;
+                                       // measured 4.5 / 6.0 / 7.5 / 8.0 / 10.2 us against 4.6 / 6.2 / 9.0 / 9.3 / 11.2 at 64 / 128 / 132 / 192 / 256 rows)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
   // State cache (ga3c_net_state_cache_config): the uint8 states the prediction steps read out of the transport, kept in HBM
   // in a ring of `depth` per agent, slot = request number % depth -- a train batch then names its rows (agent, request
@@ -339,6 +340,9 @@ struct ga3c_net {
   bool stop_events = true;             // GA3C_STOP_EVENTS=0: a prediction step's completion event is a hipEventRecord of its own
   bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
   bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
+  int wd_blocks_first = 0;             // ... at the front (1) or at the back (0) of that grid (GA3C_WD_BLOCKS_FIRST)
+  bool wd_step_in_conv2_dx = true;     // beyond 128 rows (split conv backward): dense1/w stepped by workgroups of their own in conv2_dx's
+                                       // launch instead of in dense1_bwd_tile's epilogue (GA3C_WD_STEP_IN_CONV2_DX=0: the epilogue)
   int wd_step_in_conv_bwd = 1;         // fused update: dense1/w stepped inside conv_bwd (GA3C_WD_STEP_IN_CONV_BWD: 0 never -- in
                                        // dense1_bwd_tile's epilogue --, 1 when conv_bwd's grid covers the 242 row groups, 2 always)
                                        // Measured: 29 us against 5.7 + 5.8 us as two launches (profiles/README.md) -- kept for the record, off
@@ -520,6 +524,8 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   const bool fused_cb = net->conv_bwd_fused && B <= 128;
   upd.defer_wd = upd.on && fused_cb && B <= net->d1b_tile_max &&
                  (net->wd_step_in_conv_bwd >= 2 || (net->wd_step_in_conv_bwd == 1 && 2 * B >= KSTEPS_DENSE));
+  // beyond the fused conv_bwd the step rides in conv2_dx (conv2_dx_wd_kernel)
+  if (upd.on && !fused_cb && B <= net->d1b_tile_max && net->wd_step_in_conv2_dx) upd.defer_wd = 1;
   if (B <= net->d1b_tile_max) {
     Dense1TileArgs d;
     d.n2 = t.f.n2; d.dd1 = t.dd1; d.wd = th + OFF_WD; d.g_wd = g + OFF_WD; d.g_bd = g + OFF_BD; d.dn2 = t.dn2; d.B = B;
@@ -528,8 +534,11 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     d.role_blocks = A + 2 < 14 ? A + 2 : 14;       // 242 tiles + the roles stay within one round of workgroups on 256 CUs
     d.tail_lds = net->d1b_tail && B > D1B_ROWS && B <= D1B_ROWS + D1B_TAIL_ROWS;
     const size_t d1b_lds = (d.tail_lds ? D1B_LDS_FLOATS_TAIL : D1B_LDS_FLOATS) * sizeof(float);
-    if (upd.on && upd.defer_wd) hipLaunchKernelGGL(dense1_bwd_tile_kernel<2>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
+    if (upd.on && upd.defer_wd && d.tail_lds) hipLaunchKernelGGL((dense1_bwd_tile_kernel<2, true>), dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
+    else if (upd.on && upd.defer_wd) hipLaunchKernelGGL(dense1_bwd_tile_kernel<2>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
+    else if (upd.on && d.tail_lds) hipLaunchKernelGGL((dense1_bwd_tile_kernel<1, true>), dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
     else if (upd.on) hipLaunchKernelGGL(dense1_bwd_tile_kernel<1>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
+    else if (d.tail_lds) hipLaunchKernelGGL((dense1_bwd_tile_kernel<0, true>), dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
     else hipLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), d1b_lds, st, d);
   } else {
     Dense1BwdArgs d;
@@ -561,9 +570,13 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
     // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
-    if (net->c2dw_occ >= 3 && B > 128 && B <= 192) hipLaunchKernelGGL(conv2_dw_kernel<3>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+    if (net->c2dw_occ >= 3 && B <= 256) hipLaunchKernelGGL(conv2_dw_kernel<3>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
     else hipLaunchKernelGGL(conv2_dw_kernel<2>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
-    hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
+    if (upd.on && upd.defer_wd)
+      hipLaunchKernelGGL(conv2_dx_wd_kernel, dim3(B + C2DX_WD_BLOCKS, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B,
+                         (const float*)(g + OFF_WD), upd, net->wd_blocks_first);
+    else
+      hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
     // workgroups = partial slabs.  Measured at batch 128 (round 2): 512 / 384 / 256 / 192 / 128 workgroups -> train step
     // 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
     // ... but uint8 states (4-byte loads per pixel, a longer chain per unit) lose 4 % at 256 (13.6 k vs 14.2 k steps/s), and the
@@ -1475,6 +1488,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
   if (const char* e = getenv("GA3C_C2DW_OCC")) net->c2dw_occ = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
+  if (const char* e = getenv("GA3C_WD_STEP_IN_CONV2_DX")) net->wd_step_in_conv2_dx = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_WD_BLOCKS_FIRST")) net->wd_blocks_first = atoi(e);
   if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
   if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
   if (const char* e = getenv("GA3C_STOP_EVENTS")) net->stop_events = atoi(e) != 0;
@@ -1499,7 +1514,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
     }
   }
   for (const void* fn : {reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<0>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<1>),
-                         reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<2>)}) {
+                         reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<2>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<0, true>),
+                         reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<1, true>), reinterpret_cast<const void*>(&dense1_bwd_tile_kernel<2, true>)}) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(D1B_LDS_FLOATS_TAIL * sizeof(float)));
     if (e != hipSuccess) {
       delete net;
@@ -2809,8 +2825,12 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       d.role_blocks = net->A + 2 < 14 ? net->A + 2 : 14;
       memset(&d.upd, 0, sizeof d.upd);
       d.tail_lds = k == "dense1_bwd_tile" && net->d1b_tail && B > D1B_ROWS && B <= D1B_ROWS + D1B_TAIL_ROWS;
-      hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024),
-                            (d.tail_lds ? D1B_LDS_FLOATS_TAIL : D1B_LDS_FLOATS) * sizeof(float), t.st, t.ev0, t.ev1, 0, d);
+      if (d.tail_lds)
+        hipExtLaunchKernelGGL((dense1_bwd_tile_kernel<0, true>), dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS_TAIL * sizeof(float),
+                              t.st, t.ev0, t.ev1, 0, d);
+      else
+        hipExtLaunchKernelGGL(dense1_bwd_tile_kernel<0>, dim3(D1B_TILES + d.role_blocks), dim3(1024), D1B_LDS_FLOATS * sizeof(float), t.st,
+                              t.ev0, t.ev1, 0, d);
     } else if (k == "heads") {
       HeadArgs h;
       memset(&h, 0, sizeof h);

@@ -74,8 +74,8 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 struct FusedUpd {
   const float* tin; float* tout; float* ms; float* mom; float* pk;   // pk: packed copies (dense1/w, conv12/w) of tout
   float lr, omr, mu, eps; int on;
-  int defer_wd;   // dense1/w is NOT stepped by the kernel that completes its gradient (dense1_bwd_tile) but by the next one
-                  // (conv_bwd), beside that kernel's MFMA phases: see wd_step_load / wd_step_apply
+  int defer_wd;   // dense1/w is NOT stepped by the kernel that completes its gradient (dense1_bwd_tile) but by a later one
+                  // (conv_bwd; conv2_dx_wd beyond 128 rows), beside that kernel's MFMA work: see wd_step_load / wd_step_apply
 };
 __device__ __forceinline__ float fused_rmsprop(const FusedUpd& u, int64_t i, float g) {
   float m = u.ms[i];
@@ -1459,7 +1459,7 @@ __device__ __forceinline__ void heads_bwd_role_wide(const HeadBwdArgs& h, int ro
 struct Dense1TileArgs {
   const float* n2; const float* dd1; const float* wd; float* g_wd; float* g_bd; float* dn2; int B;
   HeadBwdArgs hb; int role_blocks;
-  int tail_lds;      // the launch carries D1B_LDS_FLOATS_TAIL floats of LDS and D1B_ROWS < B <= D1B_ROWS + D1B_TAIL_ROWS
+  int tail_lds;      // host side only: the TAIL form is launched
   FusedUpd upd;      // on: dense1/w, dense1/b and the head parameters are stepped here (see FusedUpd)
 };
 
@@ -1467,7 +1467,11 @@ struct Dense1TileArgs {
 // 1 all of them, 2 all but dense1/w (FusedUpd::defer_wd: the next launch, conv_bwd, steps it).  A template argument rather
 // than a run-time switch so that the forms are separate kernels to a profiler: their HBM traffic differs by the optimizer's
 // 16 MB (profiles/: tools/pmc_table.py lists them as separate rows).
-template <int UPD>
+// TAIL: D1B_ROWS < B <= D1B_ROWS + D1B_TAIL_ROWS and the launch carries D1B_LDS_FLOATS_TAIL floats of LDS: the rows past the
+// chunk are worked on out of the tail area BESIDE the chunk -- one more step of the batch contraction for the dWd waves, four
+// MFMAs of the rows' dn2 tile for every wave, folded in the epilogue behind barriers that are there anyway -- instead of as a
+// second chunk (two more barriers, a second staging pass and 64 dependent MFMAs on one wave: 9.0 -> 10.9 us at 132 rows)
+template <int UPD, bool TAIL = false>
 __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) float d1b_lds[];
   if ((int)blockIdx.x >= D1B_TILES) {                       // block-uniform: the head roles, dealt round-robin
@@ -1499,24 +1503,14 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   }
   float* tdd = d1b_lds + D1B_LDS_FLOATS;                         // [5][260]  dd1 rows 128.. (tail area, a.tail_lds only)
   float* tn2 = tdd + D1B_TAIL_ROWS * D1B_DS;                     // [5][16]   their flat columns k0..k0+15
-  const bool tail = a.tail_lds != 0;                             // block-uniform
-  for (int c0 = 0; c0 < B; c0 += D1B_ROWS) {
-    const int rows = B - c0 < D1B_ROWS ? B - c0 : D1B_ROWS;      // real rows of this chunk
+  constexpr bool tail = TAIL;
+  const int trows = tail ? B - D1B_ROWS : 0;                     // 1 .. 5 rows worked on out of the tail area, beside the chunk
+  f32x4 tacc = zero4();                                          // this wave's partial of their dn2 tile (tail only)
+  for (int c0 = 0; c0 < B - trows; c0 += D1B_ROWS) {
+    const int rows = B - trows - c0 < D1B_ROWS ? B - trows - c0 : D1B_ROWS;      // real rows of this chunk
     const int prow = (rows + 15) & ~15;                          // padded to whole MFMA tiles
     if (c0) __syncthreads();                                     // everyone is done reading the previous chunk
-    if (c0 && tail) {
-      // ---- the second chunk out of the tail area: same images in dds / n2s as the loads below would leave
-      {
-        const int row = wv;                                      // prow = 16: one row per wave
-        *reinterpret_cast<f32x4*>(&dds[row * D1B_DS + 4 * lane]) = row < rows ? ld4(tdd + row * D1B_DS + 4 * lane) : zero4();
-      }
-      if (threadIdx.x < 4 * 16) {
-        const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
-        const f32x4 v = row < rows ? ld4(tn2 + row * D1B_COLS + 4 * c) : zero4();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) n2s[(4 * c + j) * D1B_NS + row] = v[j];
-      }
-    } else {
+    {
     // ---- stage: one 1 KB wave instruction per dd1 / Wd row, one per 16 rows of the flat columns
     for (int row = wv; row < prow; row += 16) {
       if (row < rows)
@@ -1585,7 +1579,50 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
           }
         }
       }
-    } else {
+      if (trows) {
+        // the tail rows' step of the batch contraction, b = 128 + 4 g + t, out of the tail area (rows past B are zeros): the
+        // same MFMAs in the same order as a second chunk's only step
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int bb = 4 * g + t;
+          const bool ok = bb < trows;
+          const float av1 = ok ? tn2[bb * D1B_COLS + r] : 0.f;
+          const float b0 = ok ? tdd[bb * D1B_DS + n0 + r] : 0.f, b1 = ok ? tdd[bb * D1B_DS + n0 + 16 + r] : 0.f;
+          bs0 += b0;
+          bs1 += b1;
+          accw[0][t & 1] = mfma(av1, b0, accw[0][t & 1]);
+          accw[1][t & 1] = mfma(av1, b1, accw[1][t & 1]);
+        }
+      }
+    }
+    if (trows) {                                                 // block-uniform
+      // ---- dn2 of the tail rows: one tile, its contraction cut over the 16 waves (k = 16 wv + 4 g + t), folded in the epilogue
+      const f32x4 xa = r < trows ? ld4(tdd + r * D1B_DS + 4 * g + 16 * wv) : zero4(), xw = ld4(wds + r * D1B_DS + 4 * g + 16 * wv);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tacc = mfma(xa[t], xw[t], tacc);
+    }
+    if (c0 && prow == 16) {                                      // block-uniform
+      // ---- dn2 of a chunk of <= 16 rows (the rows past the first 128): its one tile is 64 dependent MFMAs -- 0.85 us on ONE
+      // wave while fifteen wait -- so the contraction is cut over the 16 waves, four MFMAs each (k = 16 wv + 4 g + t), and
+      // the 16 partial tiles are folded in wave order through the LDS rows 16.. of dds that such a chunk leaves unused
+      float* ps = dds + 16 * D1B_DS;                             // [16 waves][16 rows][16 columns]
+      {
+        const f32x4 xa = ld4(dds + r * D1B_DS + 4 * g + 16 * wv), xw = ld4(wds + r * D1B_DS + 4 * g + 16 * wv);
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = mfma(xa[t], xw[t], acc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ps[wv * 256 + (4 * g + q) * 16 + r] = acc[q];
+      }
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += ps[w * 256 + row * 16 + col];
+        if (row < rows) a.dn2[(size_t)(c0 + row) * FLAT + k0 + col] = n2s[col * D1B_NS + row] > 0.f ? v : 0.f;
+      }
+    } else if (wv >= 8) {
       // ---- dn2: one 16-row tile per wave, contraction over the 256 hidden units, k = 16 s + 4 g + t
       const int m0 = (wv - 8) * 16;
       if (m0 < prow) {                                           // wave-uniform
@@ -1620,6 +1657,11 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
   // (16 bytes per lane) -- the accumulator layout would touch them in 64-byte pieces -- and all 16 waves take part
   __syncthreads();                                             // every wave is done with the staged operands
   float* gt = d1b_lds;                                         // [16][256]
+  float* tps = dds + 16 * D1B_DS;                              // [16 waves][16 rows][16 columns], past gt
+  if (trows) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tps[wv * 256 + (4 * g + q) * 16 + r] = tacc[q];
+  }
   if (wv < 8) {
     const int n0 = wv * 32;
 #pragma unroll
@@ -1640,6 +1682,13 @@ __global__ __launch_bounds__(1024) void dense1_bwd_tile_kernel(Dense1TileArgs a)
     }
   }
   __syncthreads();
+  if (trows && threadIdx.x >= 768) {                           // waves 12..15 fold the tail rows' dn2 tile, in wave order
+    const int i = threadIdx.x - 768, row = i >> 4, col = i & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += tps[w * 256 + row * 16 + col];
+    if (row < trows) a.dn2[(size_t)(D1B_ROWS + row) * FLAT + k0 + col] = tn2[row * D1B_COLS + col] > 0.f ? v : 0.f;
+  }
   {
     const int row = threadIdx.x >> 6, c4 = (threadIdx.x & 63) * 4;
     const int64_t idx = uidx;
@@ -1699,10 +1748,11 @@ __global__ __launch_bounds__(256) void dense1_bwd_kernel(Dense1BwdArgs a) {
     else dense1_dx_body<1>(a.dd1, a.wd, a.n2, a.dn2, a.B, j % a.dx_gx, j / a.dx_gx, a.dx_gx);
   }
 }
-// OCC = workgroups per CU the register budget is cut for.  2: 205 VGPRs, the grid of 4 B workgroups is one round up to 128 rows
-// (512 slots) and the 16 workgroups past it at 132 rows are a second round (6.1 -> 8.9 us).  3: <= 168 VGPRs (no loads held across
-// the MFMAs: conv2_dw_body<false>; the engine launches it with one sample per workgroup), three workgroups' LDS (3 x 53,248 B)
-// still fit a CU, one round up to 192 rows.  Same arithmetic, same bits.
+// OCC = workgroups per CU the register budget is cut for.  2: 205 VGPRs, the next sample's loads in flight during the MFMAs:
+// the form for batches whose workgroups walk several samples (B > 256).  3: 149 VGPRs, no loads held across the MFMAs
+// (conv2_dw_body<false>): three workgroups' LDS (3 x 53,248 B) fit a CU, so the 4 B workgroups of a batch are one round up to 192
+// rows instead of 128 -- 132 rows: 9.0 -> 7.5 us -- and it is no slower anywhere up to 256 rows (one sample per workgroup).
+// Same arithmetic, same bits.
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
                                                             float* __restrict__ part, int B) {
@@ -1876,8 +1926,9 @@ __device__ __forceinline__ void store_through(float* p, float v) { *p = v; }
 __device__ __forceinline__ void store_through4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 #endif
 struct WdStep { float g[4], m[4], t[4]; };
-__device__ __forceinline__ void wd_step_load(const FusedUpd& u, const float* __restrict__ g_wd, int s, WdStep& w) {
-  const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
+// q0: workgroups of fewer than 1024 threads walk the group's four row quads in passes (q = q0 + tid / 256)
+__device__ __forceinline__ void wd_step_load(const FusedUpd& u, const float* __restrict__ g_wd, int s, WdStep& w, int q0 = 0) {
+  const int n = threadIdx.x & 255, q = q0 + (threadIdx.x >> 8);
   const int64_t i0 = (int64_t)(16 * s + 4 * q) * HID + n;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1886,8 +1937,8 @@ __device__ __forceinline__ void wd_step_load(const FusedUpd& u, const float* __r
     w.t[j] = u.tin[OFF_WD + i0 + j * HID];
   }
 }
-__device__ __forceinline__ void wd_step_apply(const FusedUpd& u, int s, const WdStep& w) {
-  const int n = threadIdx.x & 255, q = threadIdx.x >> 8;
+__device__ __forceinline__ void wd_step_apply(const FusedUpd& u, int s, const WdStep& w, int q0 = 0) {
+  const int n = threadIdx.x & 255, q = q0 + (threadIdx.x >> 8);
   const int64_t i0 = OFF_WD + (int64_t)(16 * s + 4 * q) * HID + n;
   f32x4 tn;
 #pragma unroll
@@ -1904,6 +1955,30 @@ __device__ __forceinline__ void wd_step_apply(const FusedUpd& u, int s, const Wd
     store_through(u.tout + i0 + j * HID, tn[j]);
   }
   store_through4(u.pk + ((size_t)s * HID + n) * 16 + 4 * q, tn);
+}
+
+// The same step riding in conv2_dx, for batches beyond the fused conv_bwd's 128 rows (the split path: conv2_dw, conv2_dx,
+// conv1_dw).  There dense1_bwd_tile<1> carried it in its epilogue: 14.8 us in a 132-row step against 10.4 without.  conv2_dx
+// is 264 .. 512 workgroups of which a CU can hold three, bound by its MFMA chains, with 12 MB of traffic in 8.5 us: the 242
+// row groups go to 121 x 2 workgroups of their own at the FRONT of the grid (dispatched first: their loads and stores are
+// under way while the gradient workgroups stage and compute), two passes of two row quads each.
+constexpr int C2DX_WD_BLOCKS = KSTEPS_DENSE / 2;
+static_assert(KSTEPS_DENSE % 2 == 0, "conv2_dx_wd_kernel deals the row groups of dense1/w to pairs of workgroups");
+__global__ __launch_bounds__(512) void conv2_dx_wd_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
+                                                          const float* __restrict__ n1, float* __restrict__ dn1, int B,
+                                                          const float* __restrict__ g_wd, FusedUpd u, int wd_first) {
+  const int bxw = wd_first ? (int)blockIdx.x : (int)blockIdx.x - B;        // index among the step's block columns
+  const int bxc = wd_first ? (int)blockIdx.x - C2DX_WD_BLOCKS : (int)blockIdx.x;
+  if (bxw >= 0 && bxw < C2DX_WD_BLOCKS) {                      // block-uniform
+    const int s = 2 * bxw + blockIdx.y;
+    WdStep w0, w1;
+    wd_step_load(u, g_wd, s, w0, 0);
+    wd_step_load(u, g_wd, s, w1, 2);
+    wd_step_apply(u, s, w0, 0);
+    wd_step_apply(u, s, w1, 2);
+    return;
+  }
+  conv2_dx_body(dn2, w, n1, dn1, B, bxc, blockIdx.y, gridDim.x - C2DX_WD_BLOCKS);
 }
 
 // WD: the launch also applies the optimizer step u to dense1/w, whose gradient g_wd is complete since the previous launch

@@ -44,7 +44,7 @@ def nets():
 
     def get(num_actions):
         if num_actions not in made:
-            made[num_actions] = Network("gpu:0", "train_parity", num_actions, (84, 84, 4), max_batch=136, predict_lanes=1)
+            made[num_actions] = Network("gpu:0", "train_parity", num_actions, (84, 84, 4), max_batch=148, predict_lanes=1)
         return made[num_actions]
     yield get
     for n in made.values():
@@ -76,8 +76,10 @@ def _reset(net, num_actions):
     net.learning_rate, net.beta = LR, BETA
 
 
+# 133: the last size whose rows past the first 128 wait in dense1_bwd_tile's tail area (D1B_TAIL_ROWS = 5); 134 / 145: a second
+# chunk, with its dn2 tile cut over the waves (<= 16 rows) and without; beyond 128 rows dense1/w is stepped by conv2_dx_wd
 @pytest.mark.parametrize("fmt", ["f32", "u8"])
-@pytest.mark.parametrize("bsz", [128, 129, 132])
+@pytest.mark.parametrize("bsz", [128, 129, 132, 133, 134, 145])
 @pytest.mark.parametrize("num_actions", [6, 18])
 def test_production_train_step_matches_oracle(nets, num_actions, bsz, fmt):
     net = nets(num_actions)
@@ -104,7 +106,7 @@ def test_production_train_step_matches_oracle(nets, num_actions, bsz, fmt):
         off += size
 
 
-@pytest.mark.parametrize("bsz", [128, 132])
+@pytest.mark.parametrize("bsz", [128, 132, 134])
 def test_u8_and_f32_production_steps_give_the_same_bits(nets, bsz):
     net = nets(6)
     xk, x, a, y = _batch(bsz, 6, 4242 + bsz)
@@ -167,6 +169,44 @@ def test_dense1_weight_step_inside_conv_bwd_gives_the_bits_of_the_epilogue_step(
         assert np.any(outs[0][2] != 0)
     finally:
         for n in pair:
+            n.close()
+
+
+def test_split_path_scheduling_switches_leave_the_bits_alone(monkeypatch):
+    """Beyond the fused conv kernels' 128 rows (round 4): dense1/w stepped by workgroups of their own in conv2_dx's launch
+    (GA3C_WD_STEP_IN_CONV2_DX, at the back or the front of the grid: GA3C_WD_BLOCKS_FIRST), conv2_dw cut for three
+    workgroups per CU (GA3C_C2DW_OCC), dense1_bwd_tile's rows past 128 worked on out of the tail area beside the first chunk
+    (GA3C_D1B_TAIL; off: a second chunk whose dn2 tile is cut over the waves the same way).  Each moves work, none changes an
+    element's arithmetic or a sum's order: weights, `ms`, momentum and -- through the fragment-ordered copy of dense1/w --
+    the predictions after three steps are bit-identical with all of them off, at 129 / 132 / 133 (tail area), 134 / 140
+    (second chunk) and 100 rows (split path below 128: GA3C_CONV_BWD=0)."""
+    import ga3c_amd  # noqa: F401
+    import Config
+    from NetworkVP import Network
+    monkeypatch.setattr(Config.Config, "RMSPROP_MOMENTUM", 0.5)
+    monkeypatch.setenv("GA3C_CONV_BWD", "0")
+    settings = [{}, {"GA3C_WD_STEP_IN_CONV2_DX": "0", "GA3C_C2DW_OCC": "2", "GA3C_D1B_TAIL": "0"}, {"GA3C_WD_BLOCKS_FIRST": "1"}]
+    made = []
+    try:
+        for i, env in enumerate(settings):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            made.append(Network("gpu:0", "split_sw%d" % i, 6, (84, 84, 4), max_batch=140, predict_lanes=1))
+            for k in env:
+                monkeypatch.delenv(k)
+        for bsz in (100, 129, 132, 133, 134, 140):
+            xk, x, a, y = _batch(bsz, 6, 9300 + bsz)
+            outs = []
+            for n in made:
+                _reset(n, 6)
+                for xin in (x, xk, x):
+                    n.train(xin, y, a)
+                outs.append((n.get_arena(0), n.get_arena(1), n.get_arena(2)) + tuple(n.predict_p_v_logits(x[:128])))
+            for other in outs[1:]:
+                assert all(np.array_equal(g, w) for g, w in zip(outs[0], other)), bsz
+            assert np.any(outs[0][2] != 0) and not np.array_equal(outs[0][0], _flat(o.init_params(6)).astype(np.float32))
+    finally:
+        for n in made:
             n.close()
 
 

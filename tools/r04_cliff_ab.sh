@@ -1,26 +1,26 @@
 #!/bin/bash
-# Round 4, last call: the split path's two scheduling fixes at the rows a "batch = 128" trainer assembles
-# (conv2_dw cut for three workgroups per CU, dense1_bwd_tile's tail rows waiting in LDS): per-kernel times,
-# whole steps with the switches on / off, bits on / off, the train parity tests.
+# Round 4, the split path at the rows a "batch = 128" trainer assembles (129 .. 133): conv2_dw cut for three workgroups per
+# CU, dense1_bwd_tile's tail rows waiting in LDS and their dn2 tile cut over the 16 waves.  Per-kernel times, whole steps
+# with the switches on / off, the train and gradient parity tests.
 #   usage (through gpurun, from the repo root):  bash tools/r04_cliff_ab.sh
 set -o pipefail
 mkdir -p gpurun_out
 O=gpurun_out/r04_cliff_ab.txt
 : > $O
-for B in 132 129 133; do
-  echo "## B = $B (defaults: GA3C_C2DW_OCC=3 GA3C_D1B_TAIL=1)" >> $O
+for B in 132 129 140 192; do
+  echo "## B = $B (defaults: GA3C_C2DW_OCC=3 GA3C_D1B_TAIL=1 GA3C_WD_STEP_IN_CONV2_DX=1)" >> $O
   timeout -k 10 150 python tools/ktime.py --batch $B conv2_dw conv2_dw_occ3 dense1_bwd_tile_notail dense1_bwd_tile @train >> $O 2>&1 || exit 1
-  echo "## B = $B, GA3C_C2DW_OCC=2 GA3C_D1B_TAIL=0 (the build before)" >> $O
-  GA3C_C2DW_OCC=2 GA3C_D1B_TAIL=0 timeout -k 10 150 python tools/ktime.py --batch $B @train >> $O 2>&1 || exit 1
+  echo "## B = $B, GA3C_C2DW_OCC=2 GA3C_D1B_TAIL=0 GA3C_WD_STEP_IN_CONV2_DX=0" >> $O
+  GA3C_C2DW_OCC=2 GA3C_D1B_TAIL=0 GA3C_WD_STEP_IN_CONV2_DX=0 timeout -k 10 150 python tools/ktime.py --batch $B @train >> $O 2>&1 || exit 1
 done
-echo "## B = 128 (neither switch applies)" >> $O
+echo "## B = 128" >> $O
 timeout -k 10 150 python tools/ktime.py --batch 128 dense1_bwd_tile @train @predict >> $O 2>&1 || exit 1
-echo "## bits, defaults" >> $O
+echo "## bits (tools/ab_bits.py), defaults" >> $O
 timeout -k 10 200 python tools/ab_bits.py 129 132 133 134 > gpurun_out/r04_bits_new.txt 2>&1 || { cat gpurun_out/r04_bits_new.txt; exit 1; }
-GA3C_C2DW_OCC=2 GA3C_D1B_TAIL=0 timeout -k 10 200 python tools/ab_bits.py 129 132 133 134 > gpurun_out/r04_bits_old.txt 2>&1 || { cat gpurun_out/r04_bits_old.txt; exit 1; }
+GA3C_C2DW_OCC=2 GA3C_D1B_TAIL=0 GA3C_WD_STEP_IN_CONV2_DX=0 timeout -k 10 200 python tools/ab_bits.py 129 132 133 134 > gpurun_out/r04_bits_old.txt 2>&1 || { cat gpurun_out/r04_bits_old.txt; exit 1; }
 cat gpurun_out/r04_bits_new.txt >> $O
-if cmp -s gpurun_out/r04_bits_new.txt gpurun_out/r04_bits_old.txt; then echo "bits: identical with the switches off" >> $O; else echo "bits: DIFFER" >> $O; diff gpurun_out/r04_bits_new.txt gpurun_out/r04_bits_old.txt >> $O; fi
+if cmp -s gpurun_out/r04_bits_new.txt gpurun_out/r04_bits_old.txt; then echo "bits: identical with the switches off" >> $O; else echo "bits: DIFFER with the switches off" >> $O; fi
 cat $O
-timeout -k 10 400 python -m pytest tests/test_gpu_train_parity.py -x -q > gpurun_out/r04_cliff_tests.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_gpu_train_parity.py tests/test_gpu_parity.py -x -q > gpurun_out/r04_cliff_tests.log 2>&1; rc=$?
 tail -3 gpurun_out/r04_cliff_tests.log
 exit $rc
