@@ -340,6 +340,8 @@ struct ga3c_net {
   bool stop_events = true;             // GA3C_STOP_EVENTS=0: a prediction step's completion event is a hipEventRecord of its own
   bool offsets_in_args = true;         // GA3C_OFFSETS_IN_ARGS=0: the conv stack reads a scattered batch's offsets out of pinned host memory
   bool time_predictions = false;       // GA3C_TIME_PREDICTIONS=1: timing events around every prediction step (GA3C_STAT_PREDICT_GPU_NS)
+  int c1dw_blocks = 0;                 // conv1_dw workgroups = partial slabs of the split path; 0: conv1_dw_blocks() picks (GA3C_C1DW_BLOCKS)
+  bool dw_pair = true;                 // split path up to 256 rows: conv2_dw and conv1_dw in one launch behind conv2_dx (GA3C_DW_PAIR=0: two)
   int wd_blocks_first = 0;             // ... at the front (1) or at the back (0) of that grid (GA3C_WD_BLOCKS_FIRST)
   bool wd_step_in_conv2_dx = true;     // beyond 128 rows (split conv backward): dense1/w stepped by workgroups of their own in conv2_dx's
                                        // launch instead of in dense1_bwd_tile's epilogue (GA3C_WD_STEP_IN_CONV2_DX=0: the epilogue)
@@ -504,6 +506,18 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
   return GA3C_OK;
 }
 
+// conv1_dw workgroups (= partial slabs) of the split conv backward for a batch of B rows (see launch_backward)
+int conv1_dw_blocks(const ga3c_net* net, int B) {
+  const int units = B * 7;
+  int n = 512;
+  if (net->c1dw_blocks > 0) n = net->c1dw_blocks;
+  else if (B <= 256) {
+    const int one_round = 768 - 4 * B;
+    n = 5 * one_round >= units ? one_round : 256;
+  }
+  return units < n ? units : n;
+}
+
 // overlap: the caller will apply the gradients right away (train, not compute_grads): start their all-reduce as soon as
 // each part of the arena is final; returns with the train stream already waiting for the exchange
 // keep_dn1: also store dn1 (consumed on chip by the fused conv backward; kept in HBM for ga3c_net_fetch after compute_grads)
@@ -569,20 +583,36 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
     nch1 = nch2 = grid;
   } else {
     nch2 = B < 256 ? B : 256;          // sample groups = partial slabs
+    // workgroups = partial slabs.  Measured at batch 128 (round 2): 512 / 384 / 256 / 192 / 128 workgroups -> train step
+    // 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
+    // ... but uint8 states (4-byte loads per pixel, a longer chain per unit) lose 4 % at 256 (13.6 k vs 14.2 k steps/s), and the
+    // two input formats must cut the units alike to stay bit-identical: 512 for both
+    // Round 4: behind conv2_dx, conv1_dw shares ONE launch with conv2_dw (conv_dw_pair_kernel: three workgroups of either kind
+    // per CU = 768 slots).  With 768 - 4 B workgroups -- 240 at 132 rows, 3.9 units each -- the pair is one round and the slab
+    // reduction reads half as much: 132-row step 70.2 -> 66.0 us (f32), 70.0 -> 67.1 (uint8, whose staging became 16-byte loads
+    // for it: with dword loads it LOST 1.6 us at 240); 200 workgroups: 67.2.  Past ~142 rows that count would mean more than five
+    // units per workgroup: 256 (150 / 160 rows: 74.9 / 75.9 us against 77.0 / 77.9 at 512).  A function of B alone, so that
+    // every form of the step (paired or not, uint8 or f32) cuts the slabs alike and gives the same bits.
+    nch1 = conv1_dw_blocks(net, B);
+    const bool pair = net->dw_pair && B <= 256;    // conv2_dw + conv1_dw side by side in one launch, behind conv2_dx
     // conv2's two gradients are separate launches: their LDS/VGPR budgets differ too much to share one grid
-    if (net->c2dw_occ >= 3 && B <= 256) hipLaunchKernelGGL(conv2_dw_kernel<3>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
-    else hipLaunchKernelGGL(conv2_dw_kernel<2>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+    if (!pair) {
+      if (net->c2dw_occ >= 3 && B <= 256) hipLaunchKernelGGL(conv2_dw_kernel<3>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+      else hipLaunchKernelGGL(conv2_dw_kernel<2>, dim3(nch2, 4), dim3(256), 0, st, t.f.n1, t.dn2, t.slab2, B);
+    }
     if (upd.on && upd.defer_wd)
       hipLaunchKernelGGL(conv2_dx_wd_kernel, dim3(B + C2DX_WD_BLOCKS, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B,
                          (const float*)(g + OFF_WD), upd, net->wd_blocks_first);
     else
       hipLaunchKernelGGL(conv2_dx_kernel, dim3(B, 2), dim3(512), 0, st, t.dn2, net->theta_pk[idx] + PK_W2DX, t.f.n1, t.dn1, B);
-    // workgroups = partial slabs.  Measured at batch 128 (round 2): 512 / 384 / 256 / 192 / 128 workgroups -> train step
-    // 68.8 / 68.7 / 68.0 / 69.8 / 73.0 us: 256 (3.5 units each, 4.2 MB of slabs instead of 8.4) is as fast
-    // ... but uint8 states (4-byte loads per pixel, a longer chain per unit) lose 4 % at 256 (13.6 k vs 14.2 k steps/s), and the
-    // two input formats must cut the units alike to stay bit-identical: 512 for both
-    nch1 = B * 7 < 512 ? B * 7 : 512;
-    if (t.f.x_u8)
+    if (pair) {
+      if (t.f.x_u8)
+        hipLaunchKernelGGL(conv_dw_pair_kernel<true>, dim3(nch1 + 4 * nch2), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7, nch1,
+                           t.f.n1, t.dn2, t.slab2, B, nch2);
+      else
+        hipLaunchKernelGGL(conv_dw_pair_kernel<false>, dim3(nch1 + 4 * nch2), dim3(256), 0, st, (const void*)t.f.x, t.dn1, t.slab1, B * 7, nch1,
+                           t.f.n1, t.dn2, t.slab2, B, nch2);
+    } else if (t.f.x_u8)
       hipLaunchKernelGGL(conv1_dw_kernel<true>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
     else
       hipLaunchKernelGGL(conv1_dw_kernel<false>, dim3(nch1), dim3(256), 0, st, (const void*)t.f.x, t.dn1, t.slab1, B * 7);
@@ -1490,6 +1520,8 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV2_DX")) net->wd_step_in_conv2_dx = atoi(e) != 0;
   if (const char* e = getenv("GA3C_WD_BLOCKS_FIRST")) net->wd_blocks_first = atoi(e);
+  if (const char* e = getenv("GA3C_DW_PAIR")) net->dw_pair = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_C1DW_BLOCKS")) net->c1dw_blocks = atoi(e) >= 1 && atoi(e) <= 512 ? atoi(e) : 0;
   if (const char* e = getenv("GA3C_TIME_PREDICTIONS")) net->time_predictions = atoi(e) != 0;
   if (const char* e = getenv("GA3C_OFFSETS_IN_ARGS")) net->offsets_in_args = atoi(e) != 0;
   if (const char* e = getenv("GA3C_STOP_EVENTS")) net->stop_events = atoi(e) != 0;
@@ -2760,6 +2792,10 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
   for (int i = 0; i < iters; ++i) {
     if (k == "conv1_fwd") {
       TL(conv1_fwd_kernel<false>, dim3(B * 7), (const void*)t.f.x, th + OFF_W1, th + OFF_B1, t.f.n1, B);
+    } else if (k == "conv1_fwd_u8") {
+      TL(conv1_fwd_kernel<true>, dim3(B * 7), (const void*)t.f.xu8, th + OFF_W1, th + OFF_B1, t.f.n1, B);
+    } else if (k == "conv1_dw_u8") {
+      TL(conv1_dw_kernel<true>, dim3(conv1_dw_blocks(net, B)), (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_fwd") {
       TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "conv_stack_fwd") {
@@ -2781,9 +2817,12 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       net->d1f_tile = keep;
       CHK(rc);
     } else if (k == "conv1_dw") {
-      TL(conv1_dw_kernel<false>, dim3(B * 7 < 512 ? B * 7 : 512), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
+      TL(conv1_dw_kernel<false>, dim3(conv1_dw_blocks(net, B)), (const void*)t.f.x, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_dw") {
       TL(conv2_dw_kernel<2>, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
+    } else if (k == "conv_dw_pair") {
+      const int nch1 = conv1_dw_blocks(net, B), nch2 = B < 256 ? B : 256;
+      TL(conv_dw_pair_kernel<false>, dim3(nch1 + 4 * nch2), (const void*)t.f.x, t.dn1, t.slab1, B * 7, nch1, t.f.n1, t.dn2, t.slab2, B, nch2);
     } else if (k == "conv2_dw_occ3") {
       TL(conv2_dw_kernel<3>, dim3(B < 256 ? B : 256, 4), t.f.n1, t.dn2, t.slab2, B);
     } else if (k == "conv2_dx") {
@@ -2845,7 +2884,7 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
       else HEADS_T(64);
 #undef HEADS_T
     } else if (k == "slab_reduce") {
-      const int nch1 = B * 7 < 512 ? B * 7 : 512, nch2 = B < 256 ? B : 256;
+      const int nch1 = conv1_dw_blocks(net, B), nch2 = B < 256 ? B : 256;
       SlabSet s1{t.slab1, nch1, SLAB1, 256 * 16, g + OFF_W1, g + OFF_B1, (SLAB1 + 63) / 64, OFF_W1, OFF_B1};
       SlabSet s2{t.slab2, nch2, SLAB2, 256 * 32, g + OFF_W2, g + OFF_B2, (SLAB2 + 63) / 64, OFF_W2, OFF_B2};
       FusedUpd noupd;

@@ -249,23 +249,57 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const void* __restric
   const int b = blockIdx.x / 7, band = blockIdx.x - b * 7;
   if (b >= B) return;                       // block-uniform guard: the grid is B * 7
   const int y_base = 4 * C1_HB * band - 2;  // image row of padded band row 0
-  // band rows -> LDS (zero fill outside the image)
-  f32x4 stage[6];
+  // band rows -> LDS (zero fill outside the image).  uint8 states as 16 x 21 pieces of 16 bytes = four pixels (336 wide loads
+  // instead of 1,408 dword loads), converted on the way into LDS; the padding columns no piece covers are zeroed apart
+  f32x4 stage[U8 ? 1 : 6];
+  uint4 raw[2];
+  constexpr int U8_PIECES = C1_RIN * (IMG / 4);
+  if constexpr (U8) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int idx = threadIdx.x + 256 * i;
-    const int row = idx / C1_PW, col = idx - row * C1_PW;
-    const int yy = y_base + row, xx = col - 2;
-    const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-    stage[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
+    for (int i = 0; i < 2; ++i) {
+      const int t = threadIdx.x + 256 * i;
+      const int row = t / (IMG / 4), grp = t - row * (IMG / 4);
+      const int yy = y_base + row;
+      const bool ok = t < U8_PIECES && (unsigned)yy < (unsigned)IMG;
+      raw[i] = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(x) + (size_t)b * XS + (size_t)(yy * IMG + 4 * grp) * 4)
+                  : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);     // 128 / 128 - 1 = 0
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int row = idx / C1_PW, col = idx - row * C1_PW;
+      const int yy = y_base + row, xx = col - 2;
+      const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+      stage[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
+    }
   }
   f32x4 wstage[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) wstage[i] = ld4(w + 4 * (threadIdx.x + 256 * i));
+  if constexpr (U8) {
+    if (threadIdx.x < 4 * C1_RIN) {
+      const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+      *reinterpret_cast<f32x4*>(&img[(row * C1_PW + (c < 2 ? c : IMG + c)) * 4]) = zero4();
+    }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int idx = threadIdx.x + 256 * i;
-    if (idx < C1_RIN * C1_PW) *reinterpret_cast<f32x4*>(&img[idx * 4]) = stage[i];
+    for (int i = 0; i < 2; ++i) {
+      const int t = threadIdx.x + 256 * i;
+      if (t < U8_PIECES) {
+        const int row = t / (IMG / 4), grp = t - row * (IMG / 4);
+        float* dst = img + (row * C1_PW + 2 + 4 * grp) * 4;
+        *reinterpret_cast<f32x4*>(dst) = px_from_u8(raw[i].x);
+        *reinterpret_cast<f32x4*>(dst + 4) = px_from_u8(raw[i].y);
+        *reinterpret_cast<f32x4*>(dst + 8) = px_from_u8(raw[i].z);
+        *reinterpret_cast<f32x4*>(dst + 12) = px_from_u8(raw[i].w);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < C1_RIN * C1_PW) *reinterpret_cast<f32x4*>(&img[idx * 4]) = stage[i];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -1179,8 +1213,8 @@ constexpr int C2DW_DN = 128 * C2;                // 4096 floats
 // requested when its turn comes -- the form for grids that give every workgroup ONE sample (gx = B)
 template <bool PF = true>
 __device__ __forceinline__ void conv2_dw_body(const float* __restrict__ n1, const float* __restrict__ dn2,
-                                                          float* __restrict__ part, int B, int bx, int by, int gx) {
-  __shared__ __attribute__((aligned(16))) float lds[C2DW_IMG + C2DW_DN];
+                                                          float* __restrict__ part, int B, int bx, int by, int gx,
+                                                          float* __restrict__ lds) {   // lds: C2DW_IMG + C2DW_DN floats
   float* img = lds;
   float* dnl = lds + C2DW_IMG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -1756,7 +1790,8 @@ __global__ __launch_bounds__(256) void dense1_bwd_kernel(Dense1BwdArgs a) {
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void conv2_dw_kernel(const float* __restrict__ n1, const float* __restrict__ dn2,
                                                             float* __restrict__ part, int B) {
-  conv2_dw_body<OCC == 2>(n1, dn2, part, B, blockIdx.x, blockIdx.y, gridDim.x);
+  __shared__ __attribute__((aligned(16))) float lds[C2DW_IMG + C2DW_DN];
+  conv2_dw_body<OCC == 2>(n1, dn2, part, B, blockIdx.x, blockIdx.y, gridDim.x, lds);
 }
 __global__ __launch_bounds__(512) void conv2_dx_kernel(const float* __restrict__ dn2, const float* __restrict__ w,
                                                        const float* __restrict__ n1, float* __restrict__ dn1, int B) {
@@ -1774,42 +1809,78 @@ constexpr int SLAB1 = 256 * 16 + 16;
 constexpr int C1DW_IMG = C1_RIN * C1_PW * 4;     // 5632 floats
 constexpr int C1DW_DN = 64 * C1;                 // 1024 floats
 
+// bid / nblk: this workgroup's index among the nblk that share the units (= partial slabs); lds: C1DW_IMG + C1DW_DN floats
 template <bool U8>
-__global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict__ x, const float* __restrict__ dn1,
-                                                          float* __restrict__ part, int nunits) {
-  __shared__ __attribute__((aligned(16))) float lds[C1DW_IMG + C1DW_DN];
+__device__ __forceinline__ void conv1_dw_body(const void* __restrict__ x, const float* __restrict__ dn1,
+                                              float* __restrict__ part, int nunits, int bid, int nblk, float* __restrict__ lds) {
   float* img = lds;
   float* dnl = lds + C1DW_IMG;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, mg = threadIdx.x >> 6;
   f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
   float bs = 0.f;
-  f32x4 simg[6], sdn;
+  f32x4 simg[U8 ? 1 : 6], sdn;
+  // uint8 states: a band's 16 rows are 16 x 21 pieces of 16 bytes (four pixels) -- 336 wide loads for 256 threads instead of
+  // 1,408 dword loads (six per thread), converted when they are written to LDS; the four padding columns of the image, which
+  // no piece covers, are zeroed once.  Same values in LDS either way.
+  constexpr int U8_PIECES = C1_RIN * (IMG / 4);              // 336
+  uint4 raw[2];
   auto fetch = [&](int unit) {
     const int b = unit / 7, band = unit - b * 7;
     const int y_base = 4 * C1_HB * band - 2;
+    if constexpr (U8) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int row = idx / C1_PW, col = idx - row * C1_PW;
-      const int yy = y_base + row, xx = col - 2;
-      const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
-      simg[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
+      for (int i = 0; i < 2; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        const int row = t / (IMG / 4), grp = t - row * (IMG / 4);
+        const int yy = y_base + row;
+        const bool ok = t < U8_PIECES && (unsigned)yy < (unsigned)IMG;
+        raw[i] = ok ? *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(x) + (size_t)b * XS + (size_t)(yy * IMG + 4 * grp) * 4)
+                    : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);   // 128 / 128 - 1 = 0: rows outside the image
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int row = idx / C1_PW, col = idx - row * C1_PW;
+        const int yy = y_base + row, xx = col - 2;
+        const bool ok = idx < C1_RIN * C1_PW && (unsigned)yy < (unsigned)IMG && (unsigned)xx < (unsigned)IMG;
+        simg[i] = ok ? load_px<U8>(x, b, yy * IMG + xx) : zero4();
+      }
     }
     const float* db = dn1 + ((size_t)b * P1 + band * C1_HB * O1) * C1;
     sdn = threadIdx.x < C1_HB * O1 * C1 / 4 ? ld4(db + 4 * threadIdx.x) : zero4();   // 252 float4, slot 63 zero
   };
-  int unit = blockIdx.x;
+  if (U8 && threadIdx.x < 4 * C1_RIN) {                      // padding columns 0, 1, 86, 87 of the 16 rows
+    const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+    *reinterpret_cast<f32x4*>(&img[(row * C1_PW + (c < 2 ? c : IMG + c)) * 4]) = zero4();
+  }
+  int unit = bid;
   if (unit < nunits) fetch(unit);
-  for (; unit < nunits; unit += gridDim.x) {
+  for (; unit < nunits; unit += nblk) {
     __syncthreads();
+    if constexpr (U8) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < C1_RIN * C1_PW) *reinterpret_cast<f32x4*>(&img[idx * 4]) = simg[i];
+      for (int i = 0; i < 2; ++i) {
+        const int t = threadIdx.x + 256 * i;
+        if (t < U8_PIECES) {
+          const int row = t / (IMG / 4), grp = t - row * (IMG / 4);
+          float* dst = img + (row * C1_PW + 2 + 4 * grp) * 4;
+          *reinterpret_cast<f32x4*>(dst) = px_from_u8(raw[i].x);
+          *reinterpret_cast<f32x4*>(dst + 4) = px_from_u8(raw[i].y);
+          *reinterpret_cast<f32x4*>(dst + 8) = px_from_u8(raw[i].z);
+          *reinterpret_cast<f32x4*>(dst + 12) = px_from_u8(raw[i].w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < C1_RIN * C1_PW) *reinterpret_cast<f32x4*>(&img[idx * 4]) = simg[i];
+      }
     }
     *reinterpret_cast<f32x4*>(&dnl[threadIdx.x * 4]) = sdn;
     __syncthreads();
-    if (unit + (int)gridDim.x < nunits) fetch(unit + gridDim.x);
+    if (unit + nblk < nunits) fetch(unit + nblk);
     // The 20 LDS operands of a step (4 pixel slots x (1 dn1 value + 4 patch values)) are read into registers of their
     // own one step AHEAD of the 16 MFMAs that consume them: left to itself hipcc re-used one register pair for every
     // read and put an lgkmcnt(0) wait in front of every second MFMA (LDS latency exposed 32 times per unit).
@@ -1847,7 +1918,7 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
       }
     }
   }
-  float* out = part + (size_t)blockIdx.x * SLAB1;
+  float* out = part + (size_t)bid * SLAB1;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -1855,6 +1926,31 @@ __global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict
   if (mg == 0) {
     bs += __shfl_xor(bs, 16, 64); bs += __shfl_xor(bs, 32, 64);
     if (g == 0) out[256 * 16 + r] = bs;
+  }
+}
+template <bool U8>
+__global__ __launch_bounds__(256, 2) void conv1_dw_kernel(const void* __restrict__ x, const float* __restrict__ dn1,
+                                                          float* __restrict__ part, int nunits) {
+  __shared__ __attribute__((aligned(16))) float lds[C1DW_IMG + C1DW_DN];
+  conv1_dw_body<U8>(x, dn1, part, nunits, blockIdx.x, gridDim.x, lds);
+}
+// The two weight gradients of the split path in ONE launch (batches up to 256 rows: one sample per conv2_dw workgroup).
+// They only share dn1 / dn2 as inputs (conv2_dx runs before them), both are 256-thread workgroups far from any roof of a CU
+// (19-33 % MFMA, < 2 TB/s) that spend most of their time waiting for their own staging loads: side by side on a CU -- three
+// workgroups of either kind, 53 KB of LDS each (conv1_dw uses half of it) -- they fill each other's waits, and a kernel
+// boundary goes.  The conv1_dw workgroups (two units each, the longer ones) come first in the grid.  Slabs as before.
+template <bool U8>
+__global__ __launch_bounds__(256, 3) void conv_dw_pair_kernel(const void* __restrict__ x, const float* __restrict__ dn1,
+                                                              float* __restrict__ part1, int nunits, int nblk1,
+                                                              const float* __restrict__ n1, const float* __restrict__ dn2,
+                                                              float* __restrict__ part2, int B, int nch2) {
+  __shared__ __attribute__((aligned(16))) float lds[C2DW_IMG + C2DW_DN];
+  static_assert(C1DW_IMG + C1DW_DN <= C2DW_IMG + C2DW_DN, "conv_dw_pair: conv1_dw's image must fit conv2_dw's LDS");
+  if ((int)blockIdx.x < nblk1) {                              // block-uniform
+    conv1_dw_body<U8>(x, dn1, part1, nunits, blockIdx.x, nblk1, lds);
+  } else {
+    const int id = blockIdx.x - nblk1;
+    conv2_dw_body<false>(n1, dn2, part2, B, id % nch2, id / nch2, nch2, lds);
   }
 }
 

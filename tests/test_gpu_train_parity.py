@@ -176,7 +176,9 @@ def test_split_path_scheduling_switches_leave_the_bits_alone(monkeypatch):
     """Beyond the fused conv kernels' 128 rows (round 4): dense1/w stepped by workgroups of their own in conv2_dx's launch
     (GA3C_WD_STEP_IN_CONV2_DX, at the back or the front of the grid: GA3C_WD_BLOCKS_FIRST), conv2_dw cut for three
     workgroups per CU (GA3C_C2DW_OCC), dense1_bwd_tile's rows past 128 worked on out of the tail area beside the first chunk
-    (GA3C_D1B_TAIL; off: a second chunk whose dn2 tile is cut over the waves the same way).  Each moves work, none changes an
+    (GA3C_D1B_TAIL; off: a second chunk whose dn2 tile is cut over the waves the same way), conv2_dw and conv1_dw side by
+    side in one launch behind conv2_dx (GA3C_DW_PAIR; the number of conv1_dw workgroups = partial slabs is a function of the
+    batch size alone).  Each moves work, none changes an
     element's arithmetic or a sum's order: weights, `ms`, momentum and -- through the fragment-ordered copy of dense1/w --
     the predictions after three steps are bit-identical with all of them off, at 129 / 132 / 133 (tail area), 134 / 140
     (second chunk) and 100 rows (split path below 128: GA3C_CONV_BWD=0)."""
@@ -185,7 +187,8 @@ def test_split_path_scheduling_switches_leave_the_bits_alone(monkeypatch):
     from NetworkVP import Network
     monkeypatch.setattr(Config.Config, "RMSPROP_MOMENTUM", 0.5)
     monkeypatch.setenv("GA3C_CONV_BWD", "0")
-    settings = [{}, {"GA3C_WD_STEP_IN_CONV2_DX": "0", "GA3C_C2DW_OCC": "2", "GA3C_D1B_TAIL": "0"}, {"GA3C_WD_BLOCKS_FIRST": "1"}]
+    settings = [{}, {"GA3C_WD_STEP_IN_CONV2_DX": "0", "GA3C_C2DW_OCC": "2", "GA3C_D1B_TAIL": "0", "GA3C_DW_PAIR": "0"},
+                {"GA3C_WD_BLOCKS_FIRST": "1"}]
     made = []
     try:
         for i, env in enumerate(settings):

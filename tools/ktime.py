@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--u8", action="store_true", help="@train / @predict on uint8-resident states (what the transport delivers)")
     ap.add_argument("names", nargs="+")
     args = ap.parse_args()
     import ga3c_amd  # noqa: F401
@@ -33,6 +34,8 @@ def main():
     nat.check(lib.ga3c_net_upload(h, nat.ptr(x), nat.ptr(y), nat.ptr(a), B))
     nat.check(lib.ga3c_net_upload_u8(h, nat.ptr(xk, nat.u8p), nat.ptr(y), nat.ptr(a), B))
     nat.check(lib.ga3c_net_upload(h, nat.ptr(x), nat.ptr(y), nat.ptr(a), B))
+    if args.u8:
+        nat.check(lib.ga3c_net_upload_u8(h, nat.ptr(xk, nat.u8p), nat.ptr(y), nat.ptr(a), B))
     ms = nat.C.c_float()
     res = {n: [] for n in args.names}
     for _ in range(args.rounds):
