@@ -327,7 +327,11 @@ struct ga3c_net {
   int c2dw_occ = 3;                    // conv2_dw up to 256 rows (one sample per workgroup): workgroups per CU its registers are cut for
                                        // (GA3C_C2DW_OCC=2: the 205-VGPR form with the next sample's loads in flight, which larger batches run;
                                        // measured 4.5 / 6.0 / 7.5 / 8.0 / 10.2 us against 4.6 / 6.2 / 9.0 / 9.3 / 11.2 at 64 / 128 / 132 / 192 / 256 rows)
-  bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: three launches)
+  bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: conv2_dx, then the two weight gradients)
+  int conv_bwd_min = 97;               // ... from this many rows on (GA3C_CONV_BWD_MIN).  Below, the split launches are faster since round 4
+                                       // (uint8 train step 44.7 / 45.6 / 48.7 / 50.3 / 55.6 us against 49.3 / 50.1 / 51.5 / 52.9 / 56.4 at
+                                       // 5 / 16 / 32 / 48 / 80 rows; 58.2 against 57.4 at 100): a small grid of the one-workgroup-per-CU kernel
+                                       // leaves most of the chip idle, the split kernels spread the same rows over more workgroups
   // State cache (ga3c_net_state_cache_config): the uint8 states the prediction steps read out of the transport, kept in HBM
   // in a ring of `depth` per agent, slot = request number % depth -- a train batch then names its rows (agent, request
   // number) and is gathered HBM to HBM instead of crossing PCIe a second time.
@@ -535,7 +539,7 @@ int launch_backward(ga3c_net* net, TrainLane& t, int idx, int B, bool overlap = 
   // dense1/w stepped inside conv_bwd, beside its MFMA phases, instead of in dense1_bwd_tile's epilogue: worth 0.5 us of the
   // 128-row step (the step's 24 MB cost conv_bwd 2.2 us where they cost the epilogue 3.5) while every workgroup of conv_bwd
   // steps ONE 16-row group; below 121 rows the groups left over are a tail and it loses 0.2 us (profiles/README.md)
-  const bool fused_cb = net->conv_bwd_fused && B <= 128;
+  const bool fused_cb = net->conv_bwd_fused && B <= 128 && B >= net->conv_bwd_min;
   upd.defer_wd = upd.on && fused_cb && B <= net->d1b_tile_max &&
                  (net->wd_step_in_conv_bwd >= 2 || (net->wd_step_in_conv_bwd == 1 && 2 * B >= KSTEPS_DENSE));
   // beyond the fused conv_bwd the step rides in conv2_dx (conv2_dx_wd_kernel)
@@ -1516,6 +1520,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1F_TILE")) net->d1f_tile = atoi(e) != 0;
   if (const char* e = getenv("GA3C_D1F_FRAG_LANES")) net->d1f_frag_lanes = atoi(e);
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
+  if (const char* e = getenv("GA3C_CONV_BWD_MIN")) net->conv_bwd_min = atoi(e);
   if (const char* e = getenv("GA3C_C2DW_OCC")) net->c2dw_occ = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV2_DX")) net->wd_step_in_conv2_dx = atoi(e) != 0;

@@ -128,11 +128,15 @@ def test_dense1_weight_step_inside_conv_bwd_gives_the_bits_of_the_epilogue_step(
     import ga3c_amd  # noqa: F401
     import Config
     from NetworkVP import Network
+    # GA3C_CONV_BWD_MIN=1: the fused conv_bwd at every size up to 128 rows (by default the split launches take batches below
+    # 97 rows since round 4, so the default network is compared from there on)
+    monkeypatch.setenv("GA3C_CONV_BWD_MIN", "1")
     monkeypatch.setenv("GA3C_WD_STEP_IN_CONV_BWD", "2")
     ref = Network("gpu:0", "wd_conv_bwd", 6, (84, 84, 4), max_batch=136, predict_lanes=1)
     monkeypatch.setenv("GA3C_WD_STEP_IN_CONV_BWD", "0")
     net = Network("gpu:0", "wd_epilogue", 6, (84, 84, 4), max_batch=136, predict_lanes=1)
     monkeypatch.delenv("GA3C_WD_STEP_IN_CONV_BWD")
+    monkeypatch.delenv("GA3C_CONV_BWD_MIN")
     dflt = nets(6)
     try:
         for bsz in (8, 40, 120, 121, 128):
@@ -143,7 +147,7 @@ def test_dense1_weight_step_inside_conv_bwd_gives_the_bits_of_the_epilogue_step(
                 for xin in (x, xk, x):
                     n.train(xin, y, a)
                 outs.append((n.get_arena(0), n.get_arena(1), n.predict_p_v_logits(x)))
-            for other in outs[1:]:
+            for other in outs[1:] if bsz >= 97 else outs[1:2]:
                 assert np.array_equal(outs[0][0], other[0]) and np.array_equal(outs[0][1], other[1]), bsz
                 assert all(np.array_equal(g, w) for g, w in zip(outs[0][2], other[2])), bsz
             assert not np.array_equal(outs[0][0], _flat(o.init_params(6)).astype(np.float32))
@@ -153,10 +157,12 @@ def test_dense1_weight_step_inside_conv_bwd_gives_the_bits_of_the_epilogue_step(
     # momentum: a Network reads the optimizer's constants from Config when it is created
     monkeypatch.setattr(Config.Config, "RMSPROP_MOMENTUM", 0.5)
     pair = []
+    monkeypatch.setenv("GA3C_CONV_BWD_MIN", "1")
     for flag in ("2", "0"):
         monkeypatch.setenv("GA3C_WD_STEP_IN_CONV_BWD", flag)
         pair.append(Network("gpu:0", "wd_mom" + flag, 6, (84, 84, 4), max_batch=136, predict_lanes=1))
     monkeypatch.delenv("GA3C_WD_STEP_IN_CONV_BWD")
+    monkeypatch.delenv("GA3C_CONV_BWD_MIN")
     try:
         xk, x, a, y = _batch(64, 6, 9164)
         outs = []
@@ -197,14 +203,14 @@ def test_split_path_scheduling_switches_leave_the_bits_alone(monkeypatch):
             made.append(Network("gpu:0", "split_sw%d" % i, 6, (84, 84, 4), max_batch=140, predict_lanes=1))
             for k in env:
                 monkeypatch.delenv(k)
-        for bsz in (100, 129, 132, 133, 134, 140):
+        for bsz in (8, 40, 100, 129, 132, 133, 134, 140):
             xk, x, a, y = _batch(bsz, 6, 9300 + bsz)
             outs = []
             for n in made:
                 _reset(n, 6)
                 for xin in (x, xk, x):
                     n.train(xin, y, a)
-                outs.append((n.get_arena(0), n.get_arena(1), n.get_arena(2)) + tuple(n.predict_p_v_logits(x[:128])))
+                outs.append((n.get_arena(0), n.get_arena(1), n.get_arena(2)) + tuple(n.predict_p_v_logits(x[:min(bsz, 128)])))
             for other in outs[1:]:
                 assert all(np.array_equal(g, w) for g, w in zip(outs[0], other)), bsz
             assert np.any(outs[0][2] != 0) and not np.array_equal(outs[0][0], _flat(o.init_params(6)).astype(np.float32))
