@@ -328,6 +328,7 @@ struct ga3c_net {
                                        // (GA3C_C2DW_OCC=2: the 205-VGPR form with the next sample's loads in flight, which larger batches run;
                                        // measured 4.5 / 6.0 / 7.5 / 8.0 / 10.2 us against 4.6 / 6.2 / 9.0 / 9.3 / 11.2 at 64 / 128 / 132 / 192 / 256 rows)
   bool conv_bwd_fused = true;          // conv2_dw + conv2_dx + conv1_dw in one launch (GA3C_CONV_BWD=0: conv2_dx, then the two weight gradients)
+  bool c2f_quarter = true;             // conv2_fwd at 129 .. 192 rows: four tiles per workgroup instead of eight (GA3C_C2F_QUARTER=0)
   int conv_bwd_min = 97;               // ... from this many rows on (GA3C_CONV_BWD_MIN).  Below, the split launches are faster since round 4
                                        // (uint8 train step 44.7 / 45.6 / 48.7 / 50.3 / 55.6 us against 49.3 / 50.1 / 51.5 / 52.9 / 56.4 at
                                        // 5 / 16 / 32 / 48 / 80 rows; 58.2 against 57.4 at 100): a small grid of the one-workgroup-per-CU kernel
@@ -482,7 +483,8 @@ int launch_forward(ga3c_net* net, const Fwd& f, int idx, int B, hipStream_t st, 
       hipLaunchKernelGGL(conv1_fwd_kernel<true>, dim3(B * 7), dim3(256), 0, st, xin, th + OFF_W1, th + OFF_B1, f.n1, B);
     else
       hipLaunchKernelGGL(conv1_fwd_kernel<false>, dim3(B * 7), dim3(256), 0, st, xin, th + OFF_W1, th + OFF_B1, f.n1, B);
-    hipLaunchKernelGGL(conv2_fwd_kernel, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
+    if (net->c2f_quarter && B > 128 && B <= 192) hipLaunchKernelGGL(conv2_fwd_kernel<true>, dim3(B * 4), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
+    else hipLaunchKernelGGL(conv2_fwd_kernel<false>, dim3(B * 2), dim3(256), 0, st, f.n1, th + OFF_W2, th + OFF_B2, f.n2, B);
   }
   const int ks = dense_ks(B);
   HeadArgs h;
@@ -1521,6 +1523,7 @@ int ga3c_net_create(const ga3c_net_config* cfg, ga3c_net** out) {
   if (const char* e = getenv("GA3C_D1F_FRAG_LANES")) net->d1f_frag_lanes = atoi(e);
   if (const char* e = getenv("GA3C_CONV_BWD")) net->conv_bwd_fused = atoi(e) != 0;
   if (const char* e = getenv("GA3C_CONV_BWD_MIN")) net->conv_bwd_min = atoi(e);
+  if (const char* e = getenv("GA3C_C2F_QUARTER")) net->c2f_quarter = atoi(e) != 0;
   if (const char* e = getenv("GA3C_C2DW_OCC")) net->c2dw_occ = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV_BWD")) net->wd_step_in_conv_bwd = atoi(e);
   if (const char* e = getenv("GA3C_WD_STEP_IN_CONV2_DX")) net->wd_step_in_conv2_dx = atoi(e) != 0;
@@ -2802,7 +2805,9 @@ int ga3c_net_time_kernel(ga3c_net* net, const char* kernel, int32_t batch, int32
     } else if (k == "conv1_dw_u8") {
       TL(conv1_dw_kernel<true>, dim3(conv1_dw_blocks(net, B)), (const void*)t.f.xu8, t.dn1, t.slab1, B * 7);
     } else if (k == "conv2_fwd") {
-      TL(conv2_fwd_kernel, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
+      TL(conv2_fwd_kernel<false>, dim3(B * 2), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
+    } else if (k == "conv2_fwd_q") {
+      TL(conv2_fwd_kernel<true>, dim3(B * 4), t.f.n1, th + OFF_W2, th + OFF_B2, t.f.n2, B);
     } else if (k == "conv_stack_fwd") {
       hipExtLaunchKernelGGL((conv_stack_fwd_kernel<false, false>), dim3(B * 2), dim3(1024), CS_LDS_FLOATS * sizeof(float), t.st,
                             t.ev0, t.ev1, 0, (const void*)t.f.x, net->theta_pk[net->latest] + PK_W1F, th + OFF_B1, net->theta_pk[net->latest] + PK_W2F, th + OFF_B2, t.f.n1, t.f.n2, B,

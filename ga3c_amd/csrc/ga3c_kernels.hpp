@@ -347,6 +347,10 @@ __global__ __launch_bounds__(256, 3) void conv1_fwd_kernel(const void* __restric
 constexpr int C2_PW = 24;                   // padded n1 width/height (1 before, 2 after)
 constexpr int C2_LDS_FLOATS = C2_PW * C2_PW * C1 + 64 * 64;
 
+// Q: a workgroup takes FOUR of the eight tiles (grid B * 4).  A unit of eight tiles is 128 MFMAs per SIMD: from 129 rows on some
+// CUs hold two units and the kernel takes the second one's MFMA time on top (5.5 -> 7.4 us at 132 rows, flat to 256); with units
+// of four tiles the heaviest CU holds three (1.5 units) at the price of staging the image twice as often.
+template <bool Q = false>
 __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restrict__ n1, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ n2,
                                                            int B) {
@@ -354,8 +358,9 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restri
   float* img = lds;                          // [24][24] pixels x 16 channels
   float* wl = lds + C2_PW * C2_PW * C1;      // [j][lane] = W2[16s+4g+t][half*16 + r]
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-  const int b = blockIdx.x >> 1, half = blockIdx.x & 1;
-  if (b >= B) return;                       // block-uniform guard: the grid is B * 2
+  const int b = Q ? blockIdx.x >> 2 : blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int rep0 = Q ? (blockIdx.x >> 1) & 1 : 0;
+  if (b >= B) return;                       // block-uniform guard: the grid is B * 2 (B * 4)
   const float* nb = n1 + (size_t)b * N1S;
   // padded image: 24*24*4 = 2304 float4 -> 9 per thread
   f32x4 stage[9];
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(256, 2) void conv2_fwd_kernel(const float* __restri
   for (int j = 0; j < 64; ++j) wr[j] = wl[j * 64 + lane];
   const float bv = bias[half * 16 + r];
 #pragma unroll
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int it = 0; it < (Q ? 1 : 2); ++it) {
+    const int rep = Q ? rep0 : it;
     const int tile = wv + 4 * rep;                   // 8 tiles cover 121 pixels
     const int ml = tile * 16 + r;
     const bool valid = ml < P2;

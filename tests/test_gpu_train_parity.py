@@ -193,7 +193,7 @@ def test_split_path_scheduling_switches_leave_the_bits_alone(monkeypatch):
     from NetworkVP import Network
     monkeypatch.setattr(Config.Config, "RMSPROP_MOMENTUM", 0.5)
     monkeypatch.setenv("GA3C_CONV_BWD", "0")
-    settings = [{}, {"GA3C_WD_STEP_IN_CONV2_DX": "0", "GA3C_C2DW_OCC": "2", "GA3C_D1B_TAIL": "0", "GA3C_DW_PAIR": "0"},
+    settings = [{}, {"GA3C_WD_STEP_IN_CONV2_DX": "0", "GA3C_C2DW_OCC": "2", "GA3C_D1B_TAIL": "0", "GA3C_DW_PAIR": "0", "GA3C_C2F_QUARTER": "0"},
                 {"GA3C_WD_BLOCKS_FIRST": "1"}]
     made = []
     try:
