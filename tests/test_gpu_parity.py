@@ -107,7 +107,10 @@ def test_activations_match_oracle(nets):
         assert np.max(np.abs(got - want)) < TOL, name
 
 
-@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 1, {}), (6, 2, {}), (6, 5, {}), (6, 37, {}), (6, 128, {}), (6, 131, {}), (6, 160, {}),
+# 96 / 97: the split conv backward below, the fused conv_bwd from 97 rows on; 131 / 143 / 150 / 160: conv2_dw + conv1_dw in one
+# launch with 768 - 4 B conv1_dw workgroups (to 142 rows) and with 256; 144: a second chunk of exactly 16 rows in dense1_bwd_tile
+@pytest.mark.parametrize("num_actions,bsz,flags", [(6, 1, {}), (6, 2, {}), (6, 5, {}), (6, 37, {}), (6, 96, {}), (6, 97, {}), (6, 128, {}),
+                                                   (6, 131, {}), (6, 143, {}), (6, 144, {}), (6, 150, {}), (6, 160, {}),
                                                    (4, 16, {}), (18, 21, {}), (1, 9, {}), (25, 7, {}), (64, 6, {})])
 def test_gradients_match_oracle(nets, num_actions, bsz, flags):
     net = nets(num_actions)
